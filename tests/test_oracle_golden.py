@@ -1,0 +1,175 @@
+"""The oracle (oracle/*.py) against the vectors captured from the reference itself.
+
+Pins SURVEY.md §8c items (1)-(9).  Bit-exact where the oracle issues the same torch-CPU
+kernels on the same shapes (single-threaded, like the capture); a few-ulp tolerance where a
+result passes through float64 python arithmetic only.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from distillation_trajectories_amd.config import Config
+from distillation_trajectories_amd.synthetic import seeded_noise, state_dict_digest
+from oracle import metrics_ref, sampler_ref, unet_ref
+
+
+@pytest.fixture(autouse=True)
+def _one_thread():
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
+def eps_fn(model):
+    sd = model.state_dict()
+    return lambda x, t, c: unet_ref.unet_forward(sd, x, t, c)
+
+
+def cond_of(mode, b):
+    return None if mode == "none" else torch.full((b, 1), 0.0 if mode == "zero" else 1.0)
+
+
+def test_same_weights_as_reference(golden, models):
+    _, meta = golden
+    for sf, digest in meta["state_dict_sha256"].items():
+        assert state_dict_digest(models(float(sf)).state_dict()) == digest
+
+
+def test_unet_forward_bit_exact(golden, models):
+    arrays, meta = golden
+    for c in meta["forward_cases"]:
+        x = seeded_noise(c["seed"], (c["b"], 3, c["h"], c["h"]))
+        t = torch.full((c["b"],), c["t"], dtype=torch.long)
+        with torch.no_grad():
+            y = eps_fn(models(c["sf"]))(x, t, cond_of(c["cond"], c["b"]))
+        assert np.array_equal(y.numpy(), arrays[c["key"]]), c
+
+
+def test_unet_activations(golden, models):
+    arrays, meta = golden
+    c = meta["activation_case"]
+    x = seeded_noise(c["seed"], (c["b"], 3, c["h"], c["h"]))
+    with torch.no_grad():
+        y, acts = unet_ref.unet_forward(models(c["sf"]).state_dict(), x, torch.tensor([c["t"]] * c["b"]),
+                                        torch.ones(c["b"], 1), return_activations=True)
+    for name in unet_ref.BLOCKS:
+        assert np.array_equal(acts[name].numpy(), arrays["act_" + name]), name
+    assert np.array_equal(y.numpy(), arrays["act_out"])
+
+
+def test_schedules_and_indices(golden):
+    arrays, meta = golden
+    for n in (20, 50, 100, 1000):
+        p = sampler_ref.diffusion_params(n)
+        for k, v in p.items():
+            assert np.array_equal(v.numpy(), arrays[f"sched{n}_{k}"]), (n, k)
+    for key, seen in meta["index_sets"].items():
+        _, ss, nt = key.split("_")
+        assert sampler_ref.psample_indices(int(ss), int(nt)) == seen
+    for c in meta["manager_cases"]:
+        assert sampler_ref.manager_indices(c["sample_steps"], c["teacher_steps"]) == c["teacher_t"]
+        assert sampler_ref.manager_indices(c["sample_steps"], c["student_steps"]) == c["student_t"]
+
+
+def test_engine_trajectories(golden, models):
+    arrays, meta = golden
+    for c in meta["engine_cases"]:
+        if c["seed"] is None:
+            torch.manual_seed(c["global_seed"])
+            noise = torch.randn(1, 3, 16, 16)
+        else:
+            noise = seeded_noise(c["seed"], (1, 3, 16, 16))
+        with torch.no_grad():
+            tr = sampler_ref.generate_trajectory(eps_fn(models(c["sf"])), noise, c["T"], seed=c["seed"], guidance_scale=c["gs"])
+        got = torch.stack(tr).numpy()
+        assert got.shape == arrays[c["key"]].shape
+        assert np.array_equal(got, arrays[c["key"]]), c
+        assert np.array_equal(got[0], noise.numpy()) and np.array_equal(got[-1], got[-2])
+
+
+def test_psample_loops(golden, models):
+    arrays, meta = golden
+    for c in meta["psample_cases"]:
+        torch.manual_seed(c["global_seed"])
+        params = sampler_ref.diffusion_params(c["sample_steps"])
+        with torch.no_grad():
+            _, tr = sampler_ref.p_sample_loop(eps_fn(models(c["sf"])), (c["b"], 3, 16, 16), c["sample_steps"], params,
+                                              num_timesteps=c["timesteps"], guidance_scale=c["w"])
+        assert np.array_equal(torch.stack(tr).numpy(), arrays[c["key"]]), c
+
+
+def _close(a, b, rel=1e-12):
+    if isinstance(b, list):
+        assert len(a) == len(b)
+        return all(_close(x, y, rel) for x, y in zip(a, b))
+    a, b = float(a), float(b)
+    if math.isnan(b):
+        return math.isnan(a)
+    return a == b or abs(a - b) <= rel * max(abs(a), abs(b))
+
+
+def _check_metrics(got, want, rel=1e-12):
+    assert set(got) == set(want)
+    for k in want:
+        assert _close(got[k], want[k], rel), (k, got[k], want[k])
+
+
+def test_manager_trajectories_and_metrics(golden, models):
+    arrays, meta = golden
+    for c in meta["manager_cases"]:
+        cfg = Config()
+        cfg.image_size, cfg.sample_steps = 16, c["sample_steps"]
+        cfg.teacher_steps, cfg.student_steps = c["teacher_steps"], c["student_steps"]
+        with torch.no_grad():
+            tt, st = sampler_ref.manager_generate(eps_fn(models(c["teacher_sf"])), eps_fn(models(c["student_sf"])), cfg, seed=c["seed"])
+        assert np.array_equal(torch.stack([x for x, _ in tt]).numpy(), arrays[c["key"] + "_teacher"])
+        assert np.array_equal(torch.stack([x for x, _ in st]).numpy(), arrays[c["key"] + "_student"])
+        np.random.seed(c["np_seed"])
+        _check_metrics(metrics_ref.compute_trajectory_metrics(tt, st), c["metrics"])
+
+
+def test_metrics_on_stored_pairs(golden):
+    arrays, meta = golden
+    for c in meta["metric_cases"]:
+        a = [torch.from_numpy(x) for x in arrays[c["key"] + "_teacher"]]
+        b = a if c["key"] == "same" else [torch.from_numpy(x) for x in arrays[c["key"] + "_student"]]
+        if "np_seed" in c:
+            np.random.seed(c["np_seed"])
+        got = metrics_ref.compute_trajectory_metrics(a, [x.clone() for x in b])
+        _check_metrics(got, c["metrics"])
+    nan_case = next(c for c in meta["metric_cases"] if c["key"] == "nan")
+    assert math.isnan(nan_case["metrics"]["trajectory_mse"])      # the fixture really exercises the NaN branch
+
+
+def test_time_dependent(golden):
+    arrays, meta = golden
+    tts = [[torch.from_numpy(x) for x in arrays[f"pair{i}_teacher"]] for i in range(4)]
+    sts = [[torch.from_numpy(x) for x in arrays[f"pair{i}_student"]] for i in range(4)]
+    got = metrics_ref.time_dependent_distances(tts, sts)
+    want = meta["time_dependent"]
+    for k in got:
+        assert _close(got[k], want[k]), k
+
+
+def test_compare_trajectories(golden, models):
+    _, meta = golden
+    c = meta["compare_case"]
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = 16, c["T"]
+    with torch.no_grad():
+        res = sampler_ref.compare_trajectories(eps_fn(models(c["teacher_sf"])), eps_fn(models(c["student_sf"])), cfg,
+                                               guidance_scales=c["guidance_scales"], num_samples=c["num_samples"])
+    for side in ("teacher_metrics", "student_metrics"):
+        for gs in c["guidance_scales"]:
+            _check_metrics(res[side][gs], c["result"][side][str(gs)])
+
+
+def test_transform_metrics(golden):
+    _, meta = golden
+    for c in meta["transform_cases"]:
+        got = metrics_ref.transform_metrics(*c["args"])
+        for k, v in c["result"].items():
+            assert _close(got[k], v), (c, k)
