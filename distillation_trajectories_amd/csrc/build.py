@@ -1,0 +1,53 @@
+"""Build libdt_hip.so in-tree with hipcc for gfx950 (no torch headers, pure HIP runtime + C ABI).
+
+``python -m distillation_trajectories_amd.csrc.build`` or ``build()`` from ``__graft_entry__``.
+The library is linked against ``libamdhip64.so.7`` by SONAME only (no rpath), so inside a Python
+process that has already imported torch it binds to the HIP runtime torch itself loaded and shares
+its streams and allocations.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["dt_conv.hip", "dt_layers.hip", "dt_update.hip", "dt_metrics.hip", "dt_unet.hip"]
+HEADERS = ["dt_internal.h", os.path.join("..", "..", "include", "dt_hip.h")]
+LIB = os.path.join(HERE, "libdt_hip.so")
+ARCH = "gfx950"
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-rtlib-add-rpath",
+           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(HERE, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError(f"hipcc failed with exit code {res.returncode}")
+    if verbose and res.stderr:
+        sys.stderr.write(res.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

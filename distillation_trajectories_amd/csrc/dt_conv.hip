@@ -1,0 +1,233 @@
+// Implicit-GEMM 3x3 / 1x1 convolution on fp32 MFMA for gfx950 (CDNA4).
+//
+// Replaces the ATen conv2d + eval-BatchNorm + ReLU (+time-bias add, +residual add) sequence of
+// reference models.py:59-83.  GEMM view: M = B*H*W output pixels (NHWC rows), N = out channels,
+// K = taps * in channels.  Exact fp32: v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain.
+//
+// Tiling: a 256-thread workgroup (4 wave64, one per SIMD) owns a BM x BN output tile and walks K in
+// chunks of 16 channels of one tap.  Per chunk the A tile [BM][16] (activations, gathered with the
+// tap's pixel shift and zero padding) and the B tile [BN][16] (weights, pre-tiled at pack time so the
+// copy is linear) are staged through LDS with register prefetch + double buffering (one barrier per
+// chunk).  Both tiles keep K contiguous per row (64 B) so a lane fetches FOUR consecutive k of its
+// row with one ds_read_b128; the 16-B slots of a row are XOR-swizzled by (row>>2)&3, which makes each
+// of ds_read_b128's 16-lane groups hit 16 distinct slots of the 256-B bank row (conflict-free).
+// The MFMA k-pairing is permuted accordingly (lane half h supplies k = 8s+4h+i for MFMA i of set s)
+// identically for A and B, so the sum over k is complete and the result layout is the standard one:
+// acc register r of lane l = D[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31], i.e. a register is a 128-B run
+// of consecutive channels for two pixel rows -> coalesced NHWC stores.
+#include "dt_internal.h"
+
+namespace dt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain dwordx4 loads, always promoted to VGPRs
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+  constexpr int WN = 2;                         // 2x2 waves
+  constexpr int MI = BM / 64, NI = BN / 64;     // 32x32 MFMA tiles per wave in m / n
+  constexpr int A_PER = BM / 64, B_PER = BN / 64;  // float4 staged per thread
+  constexpr int STAGE = (BM + BN) * 16;         // floats per LDS stage
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int HW = p.H * p.W;
+  const int CC = p.cin_p >> 4;                  // 16-channel chunks per tap
+
+  // ---- per-thread staging coordinates (fixed for the whole K walk)
+  int a_off[A_PER], a_y[A_PER], a_x[A_PER];
+  bool a_ok[A_PER];
+  int a_lds[A_PER];
+#pragma unroll
+  for (int j = 0; j < A_PER; ++j) {
+    const int q = tid + j * 256, row = q >> 2, pslot = q & 3;
+    const int lslot = pslot ^ ((row >> 2) & 3);
+    const int m = m0 + row;
+    a_ok[j] = m < p.M;
+    const int mm = a_ok[j] ? m : 0;
+    const int b = mm / HW, rem = mm - b * HW;
+    a_y[j] = rem / p.W;
+    a_x[j] = rem - a_y[j] * p.W;
+    a_off[j] = mm * p.cin_p + lslot * 4;       // M*cin_p < 2^31 is checked by the host
+    a_lds[j] = q * 4;
+  }
+  const float *wbase = p.w + (size_t)n0 * 16 + tid * 4;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // row / swizzle terms of this lane's fragment reads
+  int a_row[MI], b_row[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) a_row[mi] = wm * (MI * 32) + mi * 32 + l31;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) b_row[ni] = wn * (NI * 32) + ni * 32 + l31;
+
+  // Software pipeline, one barrier per chunk: iteration `it` issues the global loads of chunk it+1
+  // into registers, runs the MFMAs of chunk it from LDS stage it&1, then parks the registers in the
+  // other stage.  it == -1 is the prologue (loads chunk 0, no compute).
+  const int n_iter = (p.tap_hi - p.tap_lo) * CC;
+  int tap = p.tap_lo, cc = 0;
+  for (int it = -1; it < n_iter; ++it) {
+    const bool more = it + 1 < n_iter;
+    f32x4 ra[A_PER], rb[B_PER];
+    if (more) {
+      int dy = 0, dx = 0;
+      if (p.ksize == 3) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+      const int shift = (dy * p.W + dx) * p.cin_p + cc * 16;
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) {
+        const int yy = a_y[j] + dy, xx = a_x[j] + dx;
+        const bool ok = a_ok[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        ra[j] = ok ? *reinterpret_cast<const f32x4 *>(p.in + a_off[j] + shift) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const float *wt = wbase + (size_t)(tap * CC + cc) * p.n_p * 16;
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) rb[j] = *reinterpret_cast<const f32x4 *>(wt + j * 1024);
+      if (++cc == CC) { cc = 0; ++tap; }
+    }
+    if (it >= 0) {
+      const float *A = lds + (it & 1) * STAGE, *B = A + BM * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        f32x4 fa[MI], fb[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          fa[mi] = *reinterpret_cast<const f32x4 *>(A + a_row[mi] * 16 + (((2 * s + half) ^ ((a_row[mi] >> 2) & 3)) << 2));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          fb[ni] = *reinterpret_cast<const f32x4 *>(B + b_row[ni] * 16 + (((2 * s + half) ^ ((b_row[ni] >> 2) & 3)) << 2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][i], fb[ni][i], acc[mi][ni], 0, 0, 0);
+            }
+      }
+    }
+    if (more) {
+      float *A = lds + ((it + 1) & 1) * STAGE, *B = A + BM * 16;
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) *reinterpret_cast<f32x4 *>(A + a_lds[j]) = ra[j];
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) *reinterpret_cast<f32x4 *>(B + (tid + j * 256) * 4) = rb[j];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: folded BN, ReLU, time bias, residual; one 128-B channel run per (register, half)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    if (n >= p.cout_p) continue;
+    const float sc = p.scale[n], sh = p.shift[n];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m >= p.M) continue;
+        float v = acc[mi][ni][r] * sc + sh;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.tb) v += p.tb[(size_t)(m / p.m_per_tb) * p.tb_stride + n];
+        const size_t o = (size_t)m * p.cout_p + n;
+        if (p.add) v += p.add[o];
+        p.out[o] = v;
+      }
+    }
+  }
+}
+
+int launch_conv(const ConvParams &p, hipStream_t s) {
+  if (!p.in || !p.w || !p.scale || !p.shift || !p.out) return DT_E_NULL;
+  if (p.cin_p % 16 || p.cout_p % 16 || p.n_p % kNPad || p.M <= 0) return DT_E_SHAPE;
+  if ((long long)p.M * p.cin_p >= (1ll << 31) || (long long)p.M * p.cout_p >= (1ll << 31)) return DT_E_SHAPE;
+  const bool wide_n = p.n_p % 128 == 0;
+  const int bn = wide_n ? 128 : 64;
+  // prefer the 128-row tile once it still yields at least one workgroup per CU
+  const long long blocks128 = (long long)((p.M + 127) / 128) * (p.n_p / bn);
+  const bool tall_m = blocks128 >= 256;
+  const int bm = tall_m ? 128 : 64;
+  dim3 grid((p.M + bm - 1) / bm, p.n_p / bn);
+  if (tall_m && wide_n) conv_gemm_kernel<128, 128><<<grid, 256, 0, s>>>(p);
+  else if (tall_m) conv_gemm_kernel<128, 64><<<grid, 256, 0, s>>>(p);
+  else if (wide_n) conv_gemm_kernel<64, 128><<<grid, 256, 0, s>>>(p);
+  else conv_gemm_kernel<64, 64><<<grid, 256, 0, s>>>(p);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight re-tiling (runs once per model in dt_unet_create).
+// wp[((kc*n_p + n)*16) + 4*(slot ^ ((n>>2)&3)) + e] = W[n][c(k)][tap(k)],  k = kc*16 + 4*slot + e,
+// k = tap*cin_p + cp; padded input channel cp maps to real channel c through the concat split
+// (channels [0,split_c) live at [0,split_c) and channels [split_c,cin) at [split_cp, ...)).
+__global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict__ wp, int cout, int cin, int ksize,
+                                 int cin_p, int n_p, int split_c, int split_cp, size_t total) {
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int pos = idx & 15;
+    const size_t rowi = idx >> 4;
+    const int n = rowi % n_p;
+    const int kc = rowi / n_p;
+    const int pslot = pos >> 2, e = pos & 3;
+    const int lslot = pslot ^ ((n >> 2) & 3);
+    const int k = kc * 16 + lslot * 4 + e;
+    const int tap = k / cin_p, cp = k - tap * cin_p;
+    int c = -1;
+    if (cp < split_cp) { if (cp < split_c) c = cp; }
+    else { const int cc = split_c + (cp - split_cp); if (cc < cin) c = cc; }
+    float v = 0.f;
+    if (n < cout && c >= 0) v = w[((size_t)n * cin + c) * (ksize * ksize) + tap];
+    wp[idx] = v;
+  }
+}
+
+int launch_pack_conv(const float *w, float *wp, int cout, int cin, int ksize, int cin_p, int n_p, int split_c,
+                     int split_cp, hipStream_t s) {
+  const size_t total = (size_t)ksize * ksize * cin_p * n_p;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  pack_conv_kernel<<<blocks, 256, 0, s>>>(w, wp, cout, cin, ksize, cin_p, n_p, split_c, split_cp, total);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// eval BatchNorm folded to y = acc*scale + shift (reference models.py:62-63 / F.batch_norm eval):
+// scale = g / sqrt(var + 1e-5), shift = (conv_bias - mean) * scale + beta.  With g == nullptr the
+// layer is a plain conv: scale = 1, shift = conv_bias.  Padding channels get 0 / 0.
+__global__ void fold_bn_kernel(const float *cb, const float *g, const float *b, const float *mean, const float *var,
+                               float *scale, float *shift, int cout, int n_p) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_p) return;
+  float sc = 0.f, sh = 0.f;
+  if (n < cout) {
+    if (g) {
+      sc = g[n] / sqrtf(var[n] + 1e-5f);
+      sh = (cb[n] - mean[n]) * sc + b[n];
+    } else {
+      sc = 1.f;
+      sh = cb[n];
+    }
+  }
+  scale[n] = sc;
+  shift[n] = sh;
+}
+
+int launch_fold_bn(const float *cb, const float *g, const float *b, const float *mean, const float *var, float *scale,
+                   float *shift, int cout, int n_p, hipStream_t s) {
+  fold_bn_kernel<<<(n_p + 255) / 256, 256, 0, s>>>(cb, g, b, mean, var, scale, shift, cout, n_p);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+}  // namespace dt

@@ -1,0 +1,74 @@
+// Internal declarations shared by the translation units of libdt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dt_hip.h"
+
+#define DT_HIP_TRY(expr)                         \
+  do {                                           \
+    hipError_t _e = (expr);                      \
+    if (_e != hipSuccess) return (int)_e;        \
+  } while (0)
+#define DT_LAUNCH_CHECK()                        \
+  do {                                           \
+    hipError_t _e = hipGetLastError();           \
+    if (_e != hipSuccess) return (int)_e;        \
+  } while (0)
+
+namespace dt {
+
+constexpr int kChanPad = 16;   // activation channel granularity (= BK of the conv GEMM)
+constexpr int kNPad = 64;      // packed-weight N granularity (smallest BN tile)
+constexpr int kBlocks = 8;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// One convolution expressed as an implicit GEMM over NHWC activations:
+//   out[m][n] = epilogue( sum_{tap,c} in[pixel(m)+tap][c] * w[tap][c][n] )
+// with m = (b, y, x) flattened, zero padding of (ksize-1)/2.
+struct ConvParams {
+  const float *in;     // [Bt][H][W][cin_p]
+  const float *w;      // packed [taps*cin_p/16][n_p][16], 16-B slots XOR-swizzled by (n>>2)&3
+  const float *scale;  // [n_p]  folded BN scale (1 for plain convs, 0 on padding)
+  const float *shift;  // [n_p]  folded BN shift / bias
+  const float *tb;     // time-bias rows (already offset to this block's channels) or nullptr
+  const float *add;    // residual [M][cout_p] or nullptr
+  float *out;          // [M][cout_p]
+  int M, H, W;
+  int cin_p, cout_p, n_p;
+  int ksize;           // 1 or 3
+  int tap_lo, tap_hi;  // taps visited (a 1x1 image only sees the centre tap)
+  int relu;
+  int tb_stride;       // floats between time-bias rows
+  int m_per_tb;        // GEMM rows sharing one time-bias row
+};
+
+int launch_conv(const ConvParams &p, hipStream_t s);
+
+int launch_pack_conv(const float *w_oihw, float *wp, int cout, int cin, int ksize, int cin_p, int n_p,
+                     int split_c, int split_cp, hipStream_t s);
+int launch_fold_bn(const float *conv_b, const float *g, const float *b, const float *mean, const float *var,
+                   float *scale, float *shift, int cout, int n_p, hipStream_t s);
+int launch_pack_linear_rows(const float *w, const float *b, float *wp, float *bp, int out, int in, int out_p,
+                            hipStream_t s);
+
+int launch_nchw_to_nhwc(const float *x, float *out, int B, int n_pass, int C, int HW, int cp, hipStream_t s);
+int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s);
+int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p, hipStream_t s);
+int launch_head(const float *lo, const float *w, const float *bias, float *eps, int Bt, int h, int w_, int cp, int C,
+                int c_real, hipStream_t s);
+
+struct TembWeights {
+  const float *freqs;  // [half]
+  const float *w1, *b1;      // time_mlp.1  [D][D]
+  const float *wc0, *bc0;    // cond_emb.0  [D][1]
+  const float *wc2, *bc2;    // cond_emb.2  [D][D]
+  const float *wt, *bt;      // concatenated per-block time_mlp rows [tb_stride][D] (zero rows on padding)
+  int D, half, tb_stride;
+};
+int launch_time_bias(const TembWeights &tw, const int32_t *t, const float *cond, const uint8_t *present, int rows,
+                     float *out, hipStream_t s);
+
+}  // namespace dt

@@ -1,0 +1,225 @@
+// HBM-bound glue layers of the U-Net forward (NHWC, channels padded to 16) and the time-embedding
+// tower.  Reference: models.py:134-135 (MaxPool2d(2), bilinear x2 align_corners=True),
+// models.py:205-224 (upsample + concat, final upsample + 1x1 head), models.py:15-39,175-185,66-77
+// (sinusoidal embedding, time / condition MLPs, per-block time projection).
+#include "dt_internal.h"
+
+namespace dt {
+
+// x[B][C][HW] (NCHW, shared by all passes) -> out[n_pass*B][HW][cp] with zero channel padding
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restrict__ out, int B, int n_pass, int C,
+                                    int HW, int cp) {
+  const size_t total = (size_t)n_pass * B * HW * cp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % cp;
+    const size_t pix = i / cp;
+    const int hw = pix % HW;
+    const int b = (pix / HW) % B;
+    out[i] = c < C ? x[((size_t)b * C + c) * HW + hw] : 0.f;
+  }
+}
+
+int launch_nchw_to_nhwc(const float *x, float *out, int B, int n_pass, int C, int HW, int cp, hipStream_t s) {
+  const size_t total = (size_t)n_pass * B * HW * cp;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  nchw_to_nhwc_kernel<<<blocks, 256, 0, s>>>(x, out, B, n_pass, C, HW, cp);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// 2x2 max pooling, stride 2, float4 over channels
+__global__ void maxpool_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int Bt, int H, int W, int c4) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const size_t total = (size_t)Bt * Ho * Wo * c4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % c4;
+    size_t r = i / c4;
+    const int xo = r % Wo; r /= Wo;
+    const int yo = r % Ho;
+    const int b = r / Ho;
+    const float4 *p = in + (((size_t)b * H + 2 * yo) * W + 2 * xo) * c4 + c;
+    const float4 a = p[0], bq = p[c4], cq = p[(size_t)W * c4], d = p[(size_t)W * c4 + c4];
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(cq.x, d.x));
+    o.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(cq.y, d.y));
+    o.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(cq.z, d.z));
+    o.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(cq.w, d.w));
+    out[i] = o;
+  }
+}
+
+int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s) {
+  const size_t total = (size_t)Bt * (H / 2) * (W / 2) * (cp / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  maxpool_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), Bt, H, W,
+                                         cp / 4);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// bilinear source coordinates for scale factor 2 with align_corners=True (ATen
+// area_pixel_compute_scale: scale = (in-1)/(out-1), 0 when out == 1; src = scale*dst)
+__device__ inline void bilinear_src(int dst, int in, int out, int &i0, int &i1, float &l0, float &l1) {
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)dst;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+// out[b][y][x][0:c1p] = bilinear_x2(lo[b]), out[...][c1p:c1p+c2p] = skip[b][y][x]  (torch.cat dim=1)
+__global__ void upcat_kernel(const float4 *__restrict__ lo, const float4 *__restrict__ skip, float4 *__restrict__ out,
+                             int Bt, int h, int w, int c1q, int c2q) {
+  const int H = 2 * h, W = 2 * w, cq = c1q + c2q;
+  const size_t total = (size_t)Bt * H * W * cq;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = i % cq;
+    size_t r = i / cq;
+    const int x = r % W; r /= W;
+    const int y = r % H;
+    const int b = r / H;
+    float4 o;
+    if (c >= c1q) {
+      o = skip[(((size_t)b * H + y) * W + x) * c2q + (c - c1q)];
+    } else {
+      int y0, y1, x0, x1;
+      float wy0, wy1, wx0, wx1;
+      bilinear_src(y, h, H, y0, y1, wy0, wy1);
+      bilinear_src(x, w, W, x0, x1, wx0, wx1);
+      const float4 *base = lo + (size_t)b * h * w * c1q + c;
+      const float4 v00 = base[((size_t)y0 * w + x0) * c1q], v01 = base[((size_t)y0 * w + x1) * c1q];
+      const float4 v10 = base[((size_t)y1 * w + x0) * c1q], v11 = base[((size_t)y1 * w + x1) * c1q];
+      o.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
+      o.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
+      o.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
+      o.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
+    }
+    out[i] = o;
+  }
+}
+
+int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p, hipStream_t s) {
+  const size_t total = (size_t)Bt * 4 * h * w * ((c1p + c2p) / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  upcat_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(lo), reinterpret_cast<const float4 *>(skip),
+                                       reinterpret_cast<float4 *>(out), Bt, h, w, c1p / 4, c2p / 4);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// Head: eps[b][c][Y][X] = bias[c] + sum_k Wf[c][k] * bilinear_x2(lo)[b][Y][X][k]   (models.py:221-224)
+// One wave per output pixel: lanes stride the channel axis (coalesced NHWC reads), the C partial
+// dot products are reduced with __shfl_down over the 64-lane wavefront.  C <= 4.
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ lo, const float *__restrict__ wf,
+                                                   const float *__restrict__ bias, float *__restrict__ eps, int Bt,
+                                                   int h, int w, int cp, int C, int c_real) {
+  const int H = 2 * h, W = 2 * w;
+  const int lane = threadIdx.x & 63;
+  const size_t n_pix = (size_t)Bt * H * W;
+  const size_t wave0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+  const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t pix = wave0; pix < n_pix; pix += n_waves) {
+    const int x = pix % W;
+    const int y = (pix / W) % H;
+    const size_t b = pix / ((size_t)W * H);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bilinear_src(y, h, H, y0, y1, wy0, wy1);
+    bilinear_src(x, w, W, x0, x1, wx0, wx1);
+    const float *base = lo + b * h * w * cp;
+    const float *p00 = base + ((size_t)y0 * w + x0) * cp, *p01 = base + ((size_t)y0 * w + x1) * cp;
+    const float *p10 = base + ((size_t)y1 * w + x0) * cp, *p11 = base + ((size_t)y1 * w + x1) * cp;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < c_real; k += 64) {
+      const float v = wy0 * (wx0 * p00[k] + wx1 * p01[k]) + wy1 * (wx0 * p10[k] + wx1 * p11[k]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) part[c] = fmaf(wf[c * c_real + k], v, part[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      for (int off = 32; off > 0; off >>= 1) part[c] += __shfl_down(part[c], off, 64);
+    if (lane == 0)
+      for (int c = 0; c < C; ++c) eps[((b * C + c) * H + y) * W + x] = part[c] + bias[c];
+  }
+}
+
+int launch_head(const float *lo, const float *wf, const float *bias, float *eps, int Bt, int h, int w, int cp, int C,
+                int c_real, hipStream_t s) {
+  if (C > 4) return DT_E_SHAPE;
+  const size_t n_pix = (size_t)Bt * 4 * h * w;
+  const size_t blocks = (n_pix + 3) / 4;
+  head_kernel<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, s>>>(lo, wf, bias, eps, Bt, h, w, cp, C, c_real);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time-embedding tower, one workgroup per (t, cond) row.  Every output neuron is one wave-level dot
+// product (lanes stride the input axis -> coalesced weight rows, __shfl_down reduction).
+__device__ inline float wave_dot(const float *__restrict__ wrow, const float *vec, int n, int lane) {
+  float s = 0.f;
+  for (int k = lane; k < n; k += 64) s = fmaf(wrow[k], vec[k], s);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return __shfl(s, 0, 64);
+}
+
+__global__ __launch_bounds__(256) void time_bias_kernel(const TembWeights tw, const int32_t *__restrict__ t,
+                                                        const float *__restrict__ cond,
+                                                        const uint8_t *__restrict__ present, float *__restrict__ out) {
+  extern __shared__ float sm[];   // emb[D] | hid[D] | temb[D]
+  const int D = tw.D, row = blockIdx.x;
+  float *emb = sm, *hid = sm + D, *temb = sm + 2 * D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  const float tv = (float)t[row];
+  for (int k = tid; k < D; k += blockDim.x) {
+    float v = 0.f;                                  // odd D: trailing zero (models.py:33-36)
+    if (k < tw.half) v = sinf(tv * tw.freqs[k]);
+    else if (k < 2 * tw.half) v = cosf(tv * tw.freqs[k - tw.half]);
+    emb[k] = v;
+  }
+  const bool has_cond = cond != nullptr && (present == nullptr || present[row] != 0);
+  const float cv = has_cond ? cond[row] : 0.f;
+  for (int k = tid; k < D; k += blockDim.x) hid[k] = fmaxf(fmaf(tw.wc0[k], cv, tw.bc0[k]), 0.f);
+  __syncthreads();
+  for (int o = wave; o < D; o += n_waves) {
+    float v = fmaxf(wave_dot(tw.w1 + (size_t)o * D, emb, D, lane) + tw.b1[o], 0.f);
+    if (has_cond) v += wave_dot(tw.wc2 + (size_t)o * D, hid, D, lane) + tw.bc2[o];
+    if (lane == 0) temb[o] = v;
+  }
+  __syncthreads();
+  float *orow = out + (size_t)row * tw.tb_stride;
+  for (int o = wave; o < tw.tb_stride; o += n_waves) {
+    const float v = fmaxf(wave_dot(tw.wt + (size_t)o * D, temb, D, lane) + tw.bt[o], 0.f);
+    if (lane == 0) orow[o] = v;
+  }
+}
+
+int launch_time_bias(const TembWeights &tw, const int32_t *t, const float *cond, const uint8_t *present, int rows,
+                     float *out, hipStream_t s) {
+  if (rows <= 0) return DT_OK;
+  time_bias_kernel<<<rows, 256, 3 * tw.D * sizeof(float), s>>>(tw, t, cond, present, out);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// copy a Linear's rows [out][in] and bias into a zero-padded [out_p][in] / [out_p] slab
+__global__ void pack_linear_rows_kernel(const float *w, const float *b, float *wp, float *bp, int out, int in, int out_p) {
+  const size_t total = (size_t)out_p * in;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int o = i / in;
+    wp[i] = o < out ? w[i] : 0.f;
+    if (i % in == 0) bp[o] = o < out ? b[o] : 0.f;
+  }
+}
+
+int launch_pack_linear_rows(const float *w, const float *b, float *wp, float *bp, int out, int in, int out_p,
+                            hipStream_t s) {
+  const size_t total = (size_t)out_p * in;
+  pack_linear_rows_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(w, b, wp, bp, out, in, out_p);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+}  // namespace dt

@@ -1,0 +1,185 @@
+// Trajectory-metric reductions over device-resident trajectories [n][B][E] (HBM-bound).
+//
+// Reference: analysis/metrics/trajectory_metrics.py:55-231 issues ~6 torch.norm(...).item() calls per
+// step (each a device sync when the tensors live on a GPU) and 51 scipy sorts per pair.  Here every
+// (pair, step) is one workgroup that streams X_i, X_{i-1}, Y_i, Y_{i-1} once with float4 loads and
+// produces the four sums the 25 metrics are built from; partial sums are folded with __shfl_down over
+// the 64-lane wavefront and then across the 4 waves through LDS.  Sums are carried in float64 so the
+// result is within one fp32 rounding of the exact value (torch's own fp32 reduction is not closer).
+#include "dt_internal.h"
+
+namespace dt {
+
+__device__ inline double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// block-wide sum of K doubles per thread; result valid in thread 0
+template <int K>
+__device__ inline void block_sum(double (&v)[K], double *sm /* [4*K] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    v[k] = wave_sum(v[k]);
+    if (lane == 0) sm[wave * K + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = sm[k] + sm[K + k] + sm[2 * K + k] + sm[3 * K + k];
+  }
+}
+
+__global__ __launch_bounds__(256) void traj_metrics_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+                                                           int nT, int nS, int B, int E, double *__restrict__ out) {
+  __shared__ double sm[16];
+  const int b = blockIdx.x, i = blockIdx.y;
+  const int n_max = nT > nS ? nT : nS;
+  const size_t step = (size_t)B * E;
+  const float4 *xi = i < nT ? reinterpret_cast<const float4 *>(X + i * step + (size_t)b * E) : nullptr;
+  const float4 *yi = i < nS ? reinterpret_cast<const float4 *>(Y + i * step + (size_t)b * E) : nullptr;
+  // i >= 1: previous states; i == 0: the trajectory's own last state (endpoint-to-start distance)
+  const int jx = i >= 1 ? i - 1 : nT - 1, jy = i >= 1 ? i - 1 : nS - 1;
+  const float4 *xj = reinterpret_cast<const float4 *>(X + jx * step + (size_t)b * E);
+  const float4 *yj = reinterpret_cast<const float4 *>(Y + jy * step + (size_t)b * E);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int e = threadIdx.x; e < E / 4; e += 256) {
+    float4 a = make_float4(0, 0, 0, 0), c = a, pa = a, pc = a;
+    if (xi) { a = xi[e]; pa = xj[e]; }
+    if (yi) { c = yi[e]; pc = yj[e]; }
+    const float ax[4] = {a.x, a.y, a.z, a.w}, cx[4] = {c.x, c.y, c.z, c.w};
+    const float px[4] = {pa.x, pa.y, pa.z, pa.w}, qx[4] = {pc.x, pc.y, pc.z, pc.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // differences in fp32 exactly as torch forms (X_i - Y_i) before the norm
+      const float d = ax[k] - cx[k], dx = ax[k] - px[k], dy = cx[k] - qx[k];
+      if (xi && yi) acc[0] += (double)d * (double)d;
+      if (xi) acc[1] += (double)dx * (double)dx;
+      if (yi) acc[2] += (double)dy * (double)dy;
+      if (xi && yi) {
+        // i == 0 carries the endpoint term |X_last - Y_last|^2 (each trajectory's own last state)
+        const float de = px[k] - qx[k];
+        acc[3] += i >= 1 ? (double)dx * (double)dy : (double)de * (double)de;
+      }
+    }
+  }
+  block_sum<4>(acc, sm);
+  if (threadIdx.x == 0) {
+    double *o = out + ((size_t)b * n_max + i) * 4;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+  }
+}
+
+int launch_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, int E, double *out, hipStream_t s) {
+  if (!X || !Y || !out) return DT_E_NULL;
+  if (nT < 1 || nS < 1 || B < 1 || E < 4 || E % 4) return DT_E_SHAPE;
+  const int n_max = nT > nS ? nT : nS;
+  if (n_max > 65535) return DT_E_SHAPE;
+  traj_metrics_kernel<<<dim3(B, n_max), 256, 0, s>>>(X, Y, nT, nS, B, E, out);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// W1 between the empirical distributions of the coordinates of X_i and Y_i (equal sample sizes):
+// mean_k |u_(k) - v_(k)| over the order statistics.  Both samples are bitonic-sorted in LDS
+// (padded to a power of two with +inf, which sorts to the tail of BOTH arrays and cancels).
+template <int N>
+__device__ inline void bitonic_sort(float *a) {
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < N / 2; t += blockDim.x) {
+        const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+        const bool up = (lo & k) == 0;
+        const float x = a[lo], y = a[hi];
+        if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void wasserstein_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+                                                          int B, int E, const int32_t *__restrict__ index,
+                                                          const int32_t *__restrict__ index_row, int n_idx,
+                                                          double *__restrict__ out, int n) {
+  __shared__ float u[N], v[N];
+  __shared__ double sm[4];
+  const int b = blockIdx.x, i = blockIdx.y;
+  const float *x = X + ((size_t)i * B + b) * E, *y = Y + ((size_t)i * B + b) * E;
+  const int cnt = index ? n_idx : E;
+  const int32_t *idx = index ? index + ((size_t)(index_row ? index_row[b] : 0) * n + i) * n_idx : nullptr;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    float a = __builtin_inff(), c = __builtin_inff();
+    if (k < cnt) { const int e = idx ? idx[k] : k; a = x[e]; c = y[e]; }
+    u[k] = a; v[k] = c;
+  }
+  __syncthreads();
+  bitonic_sort<N>(u);
+  bitonic_sort<N>(v);
+  double acc[1] = {0.0};
+  for (int k = threadIdx.x; k < cnt; k += blockDim.x) acc[0] += fabs((double)u[k] - (double)v[k]);
+  block_sum<1>(acc, sm);
+  if (threadIdx.x == 0) out[(size_t)b * n + i] = acc[0] / (double)cnt;
+}
+
+int launch_wasserstein(const float *X, const float *Y, int n, int B, int E, const int32_t *index,
+                       const int32_t *index_row, int n_idx, double *out, hipStream_t s) {
+  if (!X || !Y || !out) return DT_E_NULL;
+  const int cnt = index ? n_idx : E;
+  if (n < 1 || B < 1 || cnt < 1 || cnt > 4096 || n > 65535) return DT_E_SHAPE;
+  dim3 grid(B, n);
+  if (cnt <= 1024) wasserstein_kernel<1024><<<grid, 256, 0, s>>>(X, Y, B, E, index, index_row, n_idx, out, n);
+  else if (cnt <= 2048) wasserstein_kernel<2048><<<grid, 256, 0, s>>>(X, Y, B, E, index, index_row, n_idx, out, n);
+  else wasserstein_kernel<4096><<<grid, 256, 0, s>>>(X, Y, B, E, index, index_row, n_idx, out, n);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// trajectory_metrics.py:239-279: the longer trajectory L (n_long states) is resampled by linear
+// interpolation (scipy interp1d, float64) onto the shorter's grid linspace(0,1,n_short); output is
+// |L'(t_i) - S_i|_2 per (pair, i) in float64, as numpy computes it on the float64 resampled points.
+__device__ inline double linspace01(int j, int n) {
+  if (n <= 1) return 0.0;
+  return j == n - 1 ? 1.0 : (double)j * (1.0 / (double)(n - 1));
+}
+
+__global__ __launch_bounds__(256) void resampled_distance_kernel(const float *__restrict__ L, const float *__restrict__ S,
+                                                                 int n_long, int n_short, int B, int E,
+                                                                 double *__restrict__ out) {
+  __shared__ double sm[4];
+  const int b = blockIdx.x, i = blockIdx.y;
+  // grids as numpy.linspace(0, 1, n) builds them: j*step with the last point forced to exactly 1
+  const double x_new = linspace01(i, n_short);
+  // interp1d: hi = searchsorted(x, x_new) clipped to [1, n-1]; lo = hi - 1
+  int hi = 1;
+  while (hi < n_long - 1 && linspace01(hi, n_long) < x_new) ++hi;
+  const int lo = hi - 1;
+  const double x_lo = linspace01(lo, n_long), x_hi = linspace01(hi, n_long);
+  const float *l0 = L + ((size_t)lo * B + b) * E, *l1 = L + ((size_t)hi * B + b) * E;
+  const float *sv = S + ((size_t)i * B + b) * E;
+  double acc[1] = {0.0};
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const double y_lo = (double)l0[e], y_hi = (double)l1[e];
+    const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+    const double yn = slope * (x_new - x_lo) + y_lo;
+    const double d = yn - (double)sv[e];
+    acc[0] += d * d;
+  }
+  block_sum<1>(acc, sm);
+  if (threadIdx.x == 0) out[(size_t)b * n_short + i] = sqrt(acc[0]);
+}
+
+int launch_resampled_distance(const float *L, const float *S, int n_long, int n_short, int B, int E, double *out,
+                              hipStream_t s) {
+  if (!L || !S || !out) return DT_E_NULL;
+  if (n_long < 2 || n_short < 1 || n_short > n_long || B < 1 || E < 1 || n_short > 65535) return DT_E_SHAPE;
+  resampled_distance_kernel<<<dim3(B, n_short), 256, 0, s>>>(L, S, n_long, n_short, B, E, out);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+}  // namespace dt

@@ -1,0 +1,335 @@
+// Host side of libdt_hip.so: the U-Net handle (packed weights), the forward launch plan, the
+// device-resident reverse-diffusion loop and the extern "C" surface declared in include/dt_hip.h.
+//
+// Plan of one forward (reference models.py:159-224), NHWC activations with channels padded to 16:
+//   x(NCHW) -> a0[Bt,H,W,16]
+//   enc1 @H      -> pool -> enc2 @H/2 -> pool -> enc3 @H/4 -> pool -> enc4 @H/8 -> pool -> bottleneck @H/16
+//   up+cat(enc4) -> dec3 @H/8 -> up+cat(enc3) -> dec2 @H/4 -> up+cat(enc2) -> dec1 @H/2 -> up + 1x1 head @H
+// Each residual block is up to three implicit-GEMM launches (1x1 skip, conv1, conv2) whose epilogues
+// carry BN/ReLU/time-bias/residual, so a forward is 8 blocks * (2..3) + 4 pools + 3 upcats + 2 = ~32 launches.
+#include <new>
+#include <vector>
+
+#include "dt_internal.h"
+
+namespace dt {
+int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec, const float *z,
+                      const int32_t *z_row, long long z_shift, const float coef[4], int has_noise, const float *w,
+                      float w_scalar, float *out, int B, int E, hipStream_t s);
+int launch_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, int E, double *out, hipStream_t s);
+int launch_wasserstein(const float *X, const float *Y, int n, int B, int E, const int32_t *index,
+                       const int32_t *index_row, int n_idx, double *out, hipStream_t s);
+int launch_resampled_distance(const float *L, const float *S, int n_long, int n_short, int B, int E, double *out,
+                              hipStream_t s);
+}  // namespace dt
+
+using namespace dt;
+
+struct BlockW {
+  int cin, cout;          // real channels
+  int cin_p, cout_p, n_p; // padded
+  int split_c, split_cp;  // concat split of the input channels (== cin, cin_p when no concat)
+  bool has_res;
+  float *w1, *w2, *wr;    // packed conv weights
+  float *s1, *h1, *s2, *h2, *sr, *hr;  // scale/shift per conv
+  int tb_off;             // channel offset of this block in a time-bias row
+};
+
+struct dt_unet {
+  dt_unet_desc desc;
+  BlockW blk[kBlocks];
+  int cp[4];              // padded dims
+  int c_in_p;             // padded image channels
+  int tb_stride;
+  float *slab;            // one device allocation holding everything below
+  size_t slab_floats;
+  TembWeights tw;
+  const float *final_w, *final_b;   // borrowed? no: copied into the slab
+};
+
+namespace {
+
+struct Bump {
+  size_t off = 0;
+  size_t take(size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; }   // 256-B aligned
+};
+
+// activation buffers of one forward, as float offsets into the workspace
+struct Plan {
+  size_t a0;
+  size_t h[kBlocks], r[kBlocks], o[kBlocks];   // conv1 out, skip out, block out
+  size_t pool[4], cat[3];
+  size_t total;
+  int H[kBlocks], W[kBlocks];                  // spatial size of each block
+};
+
+// level (power-of-two divisor of the image size) of the 8 blocks
+const int kDiv[kBlocks] = {1, 2, 4, 8, 16, 8, 4, 2};
+
+Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
+  Plan p{};
+  Bump b;
+  p.a0 = b.take((size_t)Bt * H * W * u->c_in_p);
+  for (int j = 0; j < kBlocks; ++j) {
+    const int h = H / kDiv[j], w = W / kDiv[j];
+    p.H[j] = h; p.W[j] = w;
+    const size_t px = (size_t)Bt * h * w;
+    if (j >= 1 && j <= 4) p.pool[j - 1] = b.take(px * u->blk[j].cin_p);
+    if (j >= 5) p.cat[j - 5] = b.take(px * u->blk[j].cin_p);
+    p.h[j] = b.take(px * u->blk[j].cout_p);
+    p.r[j] = u->blk[j].has_res ? b.take(px * u->blk[j].cout_p) : 0;
+    p.o[j] = b.take(px * u->blk[j].cout_p);
+  }
+  p.total = b.off;
+  return p;
+}
+
+int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
+              hipStream_t s) {
+  const BlockW &k = u->blk[j];
+  const int h = pl.H[j], w = pl.W[j];
+  ConvParams p{};
+  p.M = Bt * h * w; p.H = h; p.W = w;
+  p.cin_p = k.cin_p; p.cout_p = k.cout_p; p.n_p = k.n_p;
+  p.tb_stride = u->tb_stride; p.m_per_tb = h * w * tb_div;
+  const float *res = in;   // identity skip (cin_p == cout_p)
+  if (k.has_res) {
+    p.in = in; p.w = k.wr; p.scale = k.sr; p.shift = k.hr; p.tb = nullptr; p.add = nullptr;
+    p.out = ws + pl.r[j]; p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1; p.relu = 0;
+    int st = launch_conv(p, s);
+    if (st) return st;
+    res = ws + pl.r[j];
+  }
+  // a 1x1 image only ever sees the centre tap of a padded 3x3 kernel
+  const int lo = (h == 1 && w == 1) ? 4 : 0, hi = (h == 1 && w == 1) ? 5 : 9;
+  p.ksize = 3; p.tap_lo = lo; p.tap_hi = hi; p.relu = 1;
+  p.in = in; p.w = k.w1; p.scale = k.s1; p.shift = k.h1; p.tb = tb + k.tb_off; p.add = nullptr; p.out = ws + pl.h[j];
+  int st = launch_conv(p, s);
+  if (st) return st;
+  p.cin_p = k.cout_p;
+  p.in = ws + pl.h[j]; p.w = k.w2; p.scale = k.s2; p.shift = k.h2; p.tb = nullptr; p.add = res; p.out = ws + pl.o[j];
+  return launch_conv(p, s);
+}
+
+int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int W, const float *tb, int tb_div,
+                 float *eps, float *ws, size_t ws_bytes, hipStream_t s) {
+  if (!u || !x || !tb || !eps || !ws) return DT_E_NULL;
+  if (B < 1 || n_pass < 1 || tb_div < 1 || H < 16 || W < 16 || H % 16 || W % 16) return DT_E_SHAPE;
+  const int Bt = B * n_pass;
+  const Plan pl = make_plan(u, Bt, H, W);
+  if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
+  int st = launch_nchw_to_nhwc(x, ws + pl.a0, B, n_pass, u->desc.channels, H * W, u->c_in_p, s);
+  if (st) return st;
+  const float *cur = ws + pl.a0;
+  for (int j = 0; j < kBlocks; ++j) {
+    if (j >= 1 && j <= 4) {        // encoder: pool the previous block's output
+      st = launch_maxpool(ws + pl.o[j - 1], ws + pl.pool[j - 1], Bt, pl.H[j - 1], pl.W[j - 1], u->blk[j - 1].cout_p, s);
+      if (st) return st;
+      cur = ws + pl.pool[j - 1];
+    } else if (j >= 5) {           // decoder: upsample previous output, concat the matching encoder output
+      const int skip = 8 - j;      // dec3<-enc4(3), dec2<-enc3(2), dec1<-enc2(1)
+      st = launch_upcat(ws + pl.o[j - 1], ws + pl.o[skip], ws + pl.cat[j - 5], Bt, pl.H[j - 1], pl.W[j - 1],
+                        u->blk[j - 1].cout_p, u->blk[skip].cout_p, s);
+      if (st) return st;
+      cur = ws + pl.cat[j - 5];
+    }
+    st = run_block(u, j, cur, ws, pl, Bt, tb, tb_div, s);
+    if (st) return st;
+  }
+  return launch_head(ws + pl.o[7], u->final_w, u->final_b, eps, Bt, pl.H[7], pl.W[7], u->blk[7].cout_p,
+                     u->desc.channels, u->desc.dims[0], s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dt_abi_version(void) { return DT_ABI_VERSION; }
+
+const char *dt_status_string(int st) {
+  switch (st) {
+    case DT_OK: return "ok";
+    case DT_E_NULL: return "required pointer is NULL";
+    case DT_E_SHAPE: return "unsupported or inconsistent shape";
+    case DT_E_ARG: return "bad enum or count";
+    case DT_E_WORKSPACE: return "workspace too small";
+    default: return st > 0 ? hipGetErrorString((hipError_t)st) : "unknown dt status";
+  }
+}
+
+int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float *const *gt, void *stream,
+                   dt_unet **out) {
+  if (!desc || !bt || !gt || !out) return DT_E_NULL;
+  if (desc->channels < 1 || desc->channels > 4 || desc->temb_dim < 2) return DT_E_SHAPE;
+  for (int i = 0; i < 4; ++i)
+    if (desc->dims[i] < 1) return DT_E_SHAPE;
+  for (int i = 0; i < DT_GT_COUNT; ++i)
+    if (!gt[i]) return DT_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  dt_unet *u = new (std::nothrow) dt_unet();
+  if (!u) return (int)hipErrorOutOfMemory;
+  u->desc = *desc;
+  const int C = desc->channels, D = desc->temb_dim;
+  const int *d = desc->dims;
+  for (int i = 0; i < 4; ++i) u->cp[i] = round_up(d[i], kChanPad);
+  u->c_in_p = round_up(C, kChanPad);
+  // (cin, cout) and the concat split of the eight blocks -- models.py:138-154
+  const int cin[kBlocks] = {C, d[0], d[1], d[2], d[3], d[3] + d[3], d[2] + d[2], d[1] + d[1]};
+  const int cout[kBlocks] = {d[0], d[1], d[2], d[3], d[3], d[2], d[1], d[0]};
+  const int up_c[kBlocks] = {0, 0, 0, 0, 0, d[3], d[2], d[1]};   // channels coming from the upsampled branch
+  Bump bump;
+  size_t o_w1[kBlocks], o_w2[kBlocks], o_wr[kBlocks], o_ss[kBlocks];
+  int tb = 0;
+  for (int j = 0; j < kBlocks; ++j) {
+    BlockW &k = u->blk[j];
+    k.cin = cin[j]; k.cout = cout[j];
+    k.cout_p = round_up(cout[j], kChanPad);
+    k.n_p = round_up(cout[j], kNPad);
+    if (j >= 5) {
+      k.split_c = up_c[j]; k.split_cp = round_up(up_c[j], kChanPad);
+      k.cin_p = k.split_cp + round_up(cin[j] - up_c[j], kChanPad);
+    } else {
+      k.cin_p = round_up(cin[j], kChanPad);
+      k.split_c = cin[j]; k.split_cp = k.cin_p;
+    }
+    k.has_res = cin[j] != cout[j];
+    for (int t = 0; t < DT_BT_COUNT; ++t) {
+      const bool optional = t == DT_BT_RES_W || t == DT_BT_RES_B;
+      if (!bt[j * DT_BT_COUNT + t] && (!optional || k.has_res)) { delete u; return DT_E_NULL; }
+    }
+    o_w1[j] = bump.take((size_t)9 * k.cin_p * k.n_p);
+    o_w2[j] = bump.take((size_t)9 * k.cout_p * k.n_p);
+    o_wr[j] = k.has_res ? bump.take((size_t)k.cin_p * k.n_p) : 0;
+    o_ss[j] = bump.take((size_t)6 * k.n_p);
+    k.tb_off = tb;
+    tb += k.cout_p;
+  }
+  u->tb_stride = tb;
+  const int half = (D / 2 > 1 ? D / 2 : 1);
+  const size_t o_wt = bump.take((size_t)tb * D), o_bt = bump.take(tb);
+  const size_t o_w1g = bump.take((size_t)D * D), o_b1g = bump.take(D), o_wc0 = bump.take(D), o_bc0 = bump.take(D);
+  const size_t o_wc2 = bump.take((size_t)D * D), o_bc2 = bump.take(D), o_fr = bump.take(half);
+  const size_t o_fw = bump.take((size_t)C * d[0]), o_fb = bump.take(C);
+  u->slab_floats = bump.off;
+  hipError_t e = hipMalloc((void **)&u->slab, u->slab_floats * sizeof(float));
+  if (e != hipSuccess) { delete u; return (int)e; }
+  float *S = u->slab;
+  int st = DT_OK;
+  auto copy = [&](size_t off, const float *src, size_t n) {
+    if (st == DT_OK) {
+      hipError_t ee = hipMemcpyAsync(S + off, src, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+      if (ee != hipSuccess) st = (int)ee;
+    }
+  };
+  for (int j = 0; j < kBlocks && st == DT_OK; ++j) {
+    BlockW &k = u->blk[j];
+    const float *const *t = bt + j * DT_BT_COUNT;
+    k.w1 = S + o_w1[j]; k.w2 = S + o_w2[j]; k.wr = k.has_res ? S + o_wr[j] : nullptr;
+    float *ss = S + o_ss[j];
+    k.s1 = ss; k.h1 = ss + k.n_p; k.s2 = ss + 2 * k.n_p; k.h2 = ss + 3 * k.n_p; k.sr = ss + 4 * k.n_p; k.hr = ss + 5 * k.n_p;
+    st = launch_pack_conv(t[DT_BT_CONV1_W], k.w1, k.cout, k.cin, 3, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
+    if (!st) st = launch_pack_conv(t[DT_BT_CONV2_W], k.w2, k.cout, k.cout, 3, k.cout_p, k.n_p, k.cout, k.cout_p, s);
+    if (!st && k.has_res)
+      st = launch_pack_conv(t[DT_BT_RES_W], k.wr, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
+    if (!st) st = launch_fold_bn(t[DT_BT_CONV1_B], t[DT_BT_BN1_G], t[DT_BT_BN1_B], t[DT_BT_BN1_MEAN], t[DT_BT_BN1_VAR],
+                                 k.s1, k.h1, k.cout, k.n_p, s);
+    if (!st) st = launch_fold_bn(t[DT_BT_CONV2_B], t[DT_BT_BN2_G], t[DT_BT_BN2_B], t[DT_BT_BN2_MEAN], t[DT_BT_BN2_VAR],
+                                 k.s2, k.h2, k.cout, k.n_p, s);
+    if (!st && k.has_res)
+      st = launch_fold_bn(t[DT_BT_RES_B], nullptr, nullptr, nullptr, nullptr, k.sr, k.hr, k.cout, k.n_p, s);
+    if (!st) st = launch_pack_linear_rows(t[DT_BT_TIME_W], t[DT_BT_TIME_B], S + o_wt + (size_t)k.tb_off * D,
+                                          S + o_bt + k.tb_off, k.cout, D, k.cout_p, s);
+  }
+  copy(o_w1g, gt[DT_GT_TIME1_W], (size_t)D * D); copy(o_b1g, gt[DT_GT_TIME1_B], D);
+  copy(o_wc0, gt[DT_GT_COND0_W], D); copy(o_bc0, gt[DT_GT_COND0_B], D);
+  copy(o_wc2, gt[DT_GT_COND2_W], (size_t)D * D); copy(o_bc2, gt[DT_GT_COND2_B], D);
+  copy(o_fr, gt[DT_GT_FREQS], half);
+  copy(o_fw, gt[DT_GT_FINAL_W], (size_t)C * d[0]); copy(o_fb, gt[DT_GT_FINAL_B], C);
+  if (st != DT_OK) { (void)hipFree(u->slab); delete u; return st; }
+  u->tw = TembWeights{S + o_fr, S + o_w1g, S + o_b1g, S + o_wc0, S + o_bc0, S + o_wc2, S + o_bc2, S + o_wt, S + o_bt,
+                      D, half, tb};
+  u->final_w = S + o_fw; u->final_b = S + o_fb;
+  *out = u;
+  return DT_OK;
+}
+
+void dt_unet_destroy(dt_unet *h) {
+  if (!h) return;
+  if (h->slab) (void)hipFree(h->slab);
+  delete h;
+}
+
+int dt_unet_time_bias_stride(const dt_unet *h) { return h ? h->tb_stride : DT_E_NULL; }
+
+int dt_unet_time_bias(const dt_unet *h, const int32_t *t, const float *cond, const uint8_t *present, int rows,
+                      float *out, void *stream) {
+  if (!h || !t || !out) return DT_E_NULL;
+  if (rows < 0) return DT_E_ARG;
+  return launch_time_bias(h->tw, t, cond, present, rows, out, (hipStream_t)stream);
+}
+
+size_t dt_unet_workspace_bytes(const dt_unet *h, int batch_total, int H, int W) {
+  if (!h || batch_total < 1 || H < 16 || W < 16 || H % 16 || W % 16) return 0;
+  return make_plan(h, batch_total, H, W).total * sizeof(float);
+}
+
+int dt_unet_forward(const dt_unet *h, const float *x, int B, int n_pass, int H, int W, const float *tb, int tb_div,
+                    float *eps, void *ws, size_t ws_bytes, void *stream) {
+  return forward_impl(h, x, B, n_pass, H, W, tb, tb_div, eps, (float *)ws, ws_bytes, (hipStream_t)stream);
+}
+
+int dt_unet_debug_activation(const dt_unet *h, int batch_total, int H, int W, int which, size_t *off, int *cp,
+                             int *oh, int *ow) {
+  if (!h || !off || !cp || !oh || !ow) return DT_E_NULL;
+  if (which < 0 || which >= kBlocks || batch_total < 1 || H % 16 || W % 16) return DT_E_ARG;
+  const Plan pl = make_plan(h, batch_total, H, W);
+  *off = pl.o[which]; *cp = h->blk[which].cout_p; *oh = pl.H[which]; *ow = pl.W[which];
+  return DT_OK;
+}
+
+int dt_cfg_update(int rule, const float *x, const float *eu, const float *ec, const float *z, const int32_t *z_row,
+                  const float coef[4], int has_noise, const float *w, float w_scalar, float *out, int B, int E,
+                  void *stream) {
+  return launch_cfg_update(rule, x, eu, ec, z, z_row, 0, coef, has_noise, w, w_scalar, out, B, E, (hipStream_t)stream);
+}
+
+int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, int W, int n_steps, const float *tb,
+                         const float *coef, const int32_t *has_noise, const float *z, const int32_t *z_row,
+                         const int64_t *z_shift, const float *w, float w_scalar, float *traj, float *eps_scratch,
+                         void *ws, size_t ws_bytes, void *stream) {
+  if (!h || !tb || !coef || !has_noise || !traj || !eps_scratch || !ws) return DT_E_NULL;
+  if (n_pass < 1 || n_pass > 2 || n_steps < 0 || rule < 0 || rule > DT_RULE_MANAGER) return DT_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int E = h->desc.channels * H * W;
+  const size_t slot = (size_t)B * E;
+  for (int i = 0; i < n_steps; ++i) {
+    const float *x = traj + (size_t)i * slot;
+    float *xn = traj + (size_t)(i + 1) * slot;
+    const bool dead = rule == DT_RULE_ENGINE && !has_noise[i];   // t == 0: the prediction is never used
+    if (!dead) {
+      int st = forward_impl(h, x, B, n_pass, H, W, tb + (size_t)i * n_pass * h->tb_stride, B, eps_scratch, (float *)ws,
+                            ws_bytes, s);
+      if (st) return st;
+    }
+    int st = launch_cfg_update(rule, x, eps_scratch, n_pass == 2 ? eps_scratch + slot : nullptr, z, z_row,
+                               z_shift ? (long long)z_shift[i] : 0, coef + 4 * i, has_noise[i], w, w_scalar, xn, B, E, s);
+    if (st) return st;
+  }
+  return DT_OK;
+}
+
+int dt_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, int E, double *out, void *stream) {
+  return launch_traj_metrics(X, Y, nT, nS, B, E, out, (hipStream_t)stream);
+}
+
+int dt_traj_wasserstein(const float *X, const float *Y, int n, int B, int E, const int32_t *index,
+                        const int32_t *index_row, int n_idx, double *out, void *stream) {
+  return launch_wasserstein(X, Y, n, B, E, index, index_row, n_idx, out, (hipStream_t)stream);
+}
+
+int dt_traj_resampled_distance(const float *L, const float *S, int n_long, int n_short, int B, int E, double *out,
+                               void *stream) {
+  return launch_resampled_distance(L, S, n_long, n_short, B, E, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

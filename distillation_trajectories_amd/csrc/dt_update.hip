@@ -1,0 +1,102 @@
+// Fused classifier-free-guidance mix + reverse-diffusion update + trajectory store.
+//
+// One streaming pass replaces the ~8 elementwise ATen launches per step of the reference:
+//   eps = e_u + w*(e_c - e_u)                         utils/diffusion.py:126, trajectory_engine.py:80
+//   ENGINE : x' = c1*x - c2*eps ; x' += sigma*z       trajectory_engine.py:104-110
+//   PSAMPLE: x' = sra*(x - k*eps) + z*beta            utils/diffusion.py:149-158
+//   MANAGER: x' = (x - b*eps)/sqrt(a) ; x' += s*z     utils/trajectory_manager.py:196-203
+// x' is written straight into the next trajectory slot (which is the next step's input), so the
+// algorithmic HBM traffic is read x + read z + write x' = 3*E*4 B per sample-step, plus the eps
+// read(s).  All arithmetic is plain fp32 operators with fma contraction switched off, in the
+// reference's operation order: equal inputs give bit-identical outputs to torch CPU.
+// (HIP's __fmul_rn/__fadd_rn are header inlines compiled with contraction on, so they are not used.)
+#include "dt_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace dt {
+
+struct UpdateArgs {
+  const float *x, *eu, *ec, *z;
+  const int32_t *z_row;
+  const float *w;
+  float *out;
+  float c0, c1, c2, w_scalar;
+  long long z_shift;   // added to the z row index (rows of E floats)
+  int has_noise, B, E4;
+};
+
+template <int RULE>
+__device__ inline float step1(float x, float eps, float z, const UpdateArgs &a, bool noise) {
+  if (RULE == DT_RULE_ENGINE) {
+    const float v = a.c0 * x - a.c1 * eps;
+    return v + a.c2 * z;
+  } else if (RULE == DT_RULE_PSAMPLE) {
+    const float v = a.c0 * (x - a.c1 * eps);
+    return v + (noise ? z * a.c2 : 0.f * a.c2);
+  } else {
+    const float v = (x - a.c0 * eps) / a.c1;       // IEEE division (hipcc's default for fp32 '/')
+    return v + a.c2 * z;
+  }
+}
+
+template <int RULE>
+__global__ __launch_bounds__(256) void cfg_update_kernel(const UpdateArgs a) {
+  const size_t total = (size_t)a.B * a.E4;
+  const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
+  const float4 *eu4 = reinterpret_cast<const float4 *>(a.eu);
+  const float4 *ec4 = reinterpret_cast<const float4 *>(a.ec);
+  const float4 *z4 = reinterpret_cast<const float4 *>(a.z);
+  float4 *o4 = reinterpret_cast<float4 *>(a.out);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = i / a.E4, e = i - (size_t)b * a.E4;
+    const float4 xv = x4[i];
+    if (RULE == DT_RULE_ENGINE && !a.has_noise) { o4[i] = xv; continue; }   // t == 0: x is recorded unchanged
+    float4 ev = eu4[i];
+    if (a.ec) {
+      const float4 cv = ec4[i];
+      const float w = a.w ? a.w[b] : a.w_scalar;
+      ev.x = ev.x + w * (cv.x - ev.x);
+      ev.y = ev.y + w * (cv.y - ev.y);
+      ev.z = ev.z + w * (cv.z - ev.z);
+      ev.w = ev.w + w * (cv.w - ev.w);
+    }
+    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool noise = a.has_noise != 0;
+    if (noise) {
+      const long long zr = (a.z_row ? (long long)a.z_row[b] : (long long)b) + a.z_shift;
+      zv = z4[(size_t)zr * a.E4 + e];
+    }
+    float4 o;
+    if (RULE != DT_RULE_PSAMPLE && !noise) {
+      // MANAGER at t == 0 never reaches the update in the reference; keep the deterministic part
+      o.x = step1<RULE>(xv.x, ev.x, 0.f, a, false); o.y = step1<RULE>(xv.y, ev.y, 0.f, a, false);
+      o.z = step1<RULE>(xv.z, ev.z, 0.f, a, false); o.w = step1<RULE>(xv.w, ev.w, 0.f, a, false);
+    } else {
+      o.x = step1<RULE>(xv.x, ev.x, zv.x, a, noise); o.y = step1<RULE>(xv.y, ev.y, zv.y, a, noise);
+      o.z = step1<RULE>(xv.z, ev.z, zv.z, a, noise); o.w = step1<RULE>(xv.w, ev.w, zv.w, a, noise);
+    }
+    o4[i] = o;
+  }
+}
+
+int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec, const float *z,
+                      const int32_t *z_row, long long z_shift, const float coef[4], int has_noise, const float *w,
+                      float w_scalar, float *out, int B, int E, hipStream_t s) {
+  if (!x || !eu || !out || !coef) return DT_E_NULL;
+  if (has_noise && !z) return DT_E_NULL;
+  if (B <= 0 || E <= 0 || E % 4) return DT_E_SHAPE;
+  UpdateArgs a{x, eu, ec, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4};
+  const size_t total = (size_t)B * (E / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  switch (rule) {
+    case DT_RULE_ENGINE: cfg_update_kernel<DT_RULE_ENGINE><<<blocks, 256, 0, s>>>(a); break;
+    case DT_RULE_PSAMPLE: cfg_update_kernel<DT_RULE_PSAMPLE><<<blocks, 256, 0, s>>>(a); break;
+    case DT_RULE_MANAGER: cfg_update_kernel<DT_RULE_MANAGER><<<blocks, 256, 0, s>>>(a); break;
+    default: return DT_E_ARG;
+  }
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+}  // namespace dt

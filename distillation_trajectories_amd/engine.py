@@ -1,0 +1,299 @@
+"""Host-side driver of the HIP path: weight hand-off, time-bias tables, device-resident
+reverse loops and metric post-processing.  PyTorch is used for device memory, streams and
+host<->device copies only; all arithmetic on trajectories happens in csrc/ kernels.
+
+Everything here raises if the HIP library is missing or a tensor is not on a CUDA(HIP)
+device -- the product has no CPU path (the CPU restatement lives in oracle/ and is test-only).
+"""
+import ctypes
+import math
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import (COND_NONE, COND_ONE, COND_ZERO, RULE_ENGINE, RULE_MANAGER, RULE_PSAMPLE, HipLibraryError, check,
+                   ptr, stream_ptr)
+
+BLOCK_NAMES = ("enc1", "enc2", "enc3", "enc4", "bottleneck", "dec3", "dec2", "dec1")
+_BLOCK_KEYS = ("time_mlp.weight", "time_mlp.bias",
+               "conv1.weight", "conv1.bias", "norm1.weight", "norm1.bias", "norm1.running_mean", "norm1.running_var",
+               "conv2.weight", "conv2.bias", "norm2.weight", "norm2.bias", "norm2.running_mean", "norm2.running_var",
+               "residual_conv.weight", "residual_conv.bias")
+_GLOBAL_KEYS = ("time_mlp.1.weight", "time_mlp.1.bias", "cond_emb.0.weight", "cond_emb.0.bias",
+                "cond_emb.2.weight", "cond_emb.2.bias", "final.weight", "final.bias")
+
+
+def _require_cuda(t, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipLibraryError(f"{what} must be a CUDA(HIP) tensor: the MI355X path has no CPU fallback "
+                              "(the CPU restatement lives in oracle/ and is for tests only)")
+
+
+def sinusoid_frequencies(dim):
+    """models.py:17-21: exp(arange(half) * -(ln 1e4 / (half-1+1e-8))) with torch's fp32 dtype path."""
+    half = max(max(dim, 2) // 2, 1)
+    return torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1 + 1e-8)))
+
+
+class UNetHandle:
+    """Owns one ``dt_unet`` (packed weights in HBM) built from a module's state_dict."""
+
+    def __init__(self, state_dict, device):
+        self.lib = _hip.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise HipLibraryError("models must live on a CUDA(HIP) device; there is no CPU fallback")
+        sd = {k: v.detach().to(device=self.device, dtype=torch.float32).contiguous()
+              for k, v in state_dict.items() if v.dtype.is_floating_point}
+        self.channels = sd["final.weight"].shape[0]
+        self.temb_dim = sd["time_mlp.1.weight"].shape[0]
+        self.dims = [sd[f"{n}.conv1.weight"].shape[0] for n in ("enc1", "enc2", "enc3", "enc4")]
+        desc = _hip.UNetDesc(self.channels, (c_int32 * 4)(*self.dims), self.temb_dim)
+        bt = (c_void_p * (_hip.N_BLOCKS * _hip.BT_COUNT))()
+        for j, name in enumerate(BLOCK_NAMES):
+            for i, key in enumerate(_BLOCK_KEYS):
+                t = sd.get(f"{name}.{key}")
+                bt[j * _hip.BT_COUNT + i] = t.data_ptr() if t is not None else None
+        freqs = sinusoid_frequencies(self.temb_dim).to(self.device)
+        gt = (c_void_p * _hip.GT_COUNT)(*[sd[k].data_ptr() for k in _GLOBAL_KEYS], freqs.data_ptr())
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.dt_unet_create(ctypes.byref(desc), bt, gt, stream_ptr(), ctypes.byref(h)), "dt_unet_create")
+            torch.cuda.current_stream().synchronize()   # sd / freqs may be freed after this
+        self.h = h
+        self.tb_stride = self.lib.dt_unet_time_bias_stride(self.h)
+        self._ws = {}
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.dt_unet_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ caching per nn.Module
+    @staticmethod
+    def for_module(module):
+        """Handle cached on the module; rebuilt when any weight tensor was replaced or mutated."""
+        sd = module.state_dict()
+        first = next(iter(sd.values()))
+        _require_cuda(first, "model parameters")
+        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        cached = module.__dict__.get("_dt_hip_handle")
+        if cached is None or cached[0] != key:
+            cached = (key, UNetHandle(sd, first.device))
+            module.__dict__["_dt_hip_handle"] = cached
+        return cached[1]
+
+    # ------------------------------------------------------------------ primitives
+    def workspace(self, batch_total, H, W):
+        key = (batch_total, H, W)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = self.lib.dt_unet_workspace_bytes(self.h, batch_total, H, W)
+            if n == 0:
+                raise HipLibraryError(f"unsupported shape batch={batch_total} H={H} W={W} (H, W must be multiples of 16)")
+            if len(self._ws) > 4:
+                self._ws.clear()
+            ws = self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def time_bias(self, t_values, cond_modes):
+        """[rows, tb_stride] table for rows (t_values[i], cond_modes[i]); cond mode in {NONE, ZERO, ONE}."""
+        rows = len(t_values)
+        t = torch.tensor(list(t_values), dtype=torch.int32).to(self.device)
+        cond = torch.tensor([1.0 if m == COND_ONE else 0.0 for m in cond_modes], dtype=torch.float32).to(self.device)
+        present = torch.tensor([0 if m == COND_NONE else 1 for m in cond_modes], dtype=torch.uint8).to(self.device)
+        return self.time_bias_general(t, cond, present, rows)
+
+    def time_bias_general(self, t_i32, cond_f32, present_u8, rows):
+        out = torch.empty(rows, self.tb_stride, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.dt_unet_time_bias(self.h, ptr(t_i32), ptr(cond_f32), ptr(present_u8), rows, ptr(out),
+                                             stream_ptr()), "dt_unet_time_bias")
+        return out
+
+    def forward(self, x, tb, n_pass, tb_div):
+        """eps[n_pass*B,C,H,W] for x[B,C,H,W]; tb rows as documented in dt_hip.h."""
+        _require_cuda(x, "x")
+        x = x.contiguous().float()
+        B, C, H, W = x.shape
+        if C != self.channels:
+            raise HipLibraryError(f"x has {C} channels, the model expects {self.channels}")
+        eps = torch.empty(n_pass * B, C, H, W, dtype=torch.float32, device=self.device)
+        ws = self.workspace(n_pass * B, H, W)
+        with torch.cuda.device(self.device):
+            check(self.lib.dt_unet_forward(self.h, ptr(x), B, n_pass, H, W, ptr(tb), tb_div, ptr(eps), ptr(ws),
+                                           c_size_t(ws.numel()), stream_ptr()), "dt_unet_forward")
+        return eps
+
+    def debug_activation(self, batch_total, H, W, which):
+        """NHWC view [Bt,h,w,cp] of block ``which``'s output inside the workspace of the last forward."""
+        off, cp, oh, ow = c_size_t(), c_int(), c_int(), c_int()
+        check(self.lib.dt_unet_debug_activation(self.h, batch_total, H, W, which, ctypes.byref(off), ctypes.byref(cp),
+                                                ctypes.byref(oh), ctypes.byref(ow)), "dt_unet_debug_activation")
+        ws = self.workspace(batch_total, H, W).view(torch.float32)
+        n = batch_total * oh.value * ow.value * cp.value
+        return ws[off.value: off.value + n].view(batch_total, oh.value, ow.value, cp.value)
+
+    def sample(self, rule, traj, H, W, tb, n_pass, coef, has_noise, z=None, z_row=None, z_shift=None, w=None,
+               w_scalar=1.0):
+        """Run len(coef) reverse steps in place on traj[(n_steps+1), B, E] (slot 0 = x_T)."""
+        _require_cuda(traj, "traj")
+        n_steps = len(coef)
+        B = traj.shape[1]
+        assert traj.shape[0] == n_steps + 1 and traj.is_contiguous() and traj.dtype == torch.float32
+        coef_c = (c_float * (4 * n_steps))(*[float(v) for row in coef for v in (list(row) + [0.0] * 4)[:4]])
+        noise_c = (c_int32 * n_steps)(*[int(bool(v)) for v in has_noise])
+        shift_c = (c_int64 * n_steps)(*[int(v) for v in (z_shift if z_shift is not None else [0] * n_steps)])
+        eps = torch.empty(n_pass, B, traj.shape[2], dtype=torch.float32, device=self.device)
+        ws = self.workspace(n_pass * B, H, W)
+        with torch.cuda.device(self.device):
+            check(self.lib.dt_sample_trajectory(self.h, rule, B, n_pass, H, W, n_steps, ptr(tb), coef_c, noise_c,
+                                                ptr(z), ptr(z_row), shift_c, ptr(w), c_float(w_scalar), ptr(traj),
+                                                ptr(eps), ptr(ws), c_size_t(ws.numel()), stream_ptr()),
+                  "dt_sample_trajectory")
+        return traj
+
+
+def cfg_update(rule, x, eps_u, eps_c, z, coef, has_noise, w=None, w_scalar=1.0, z_row=None):
+    """One fused CFG-mix + update step (dt_cfg_update); returns the new x."""
+    lib = _hip.load()
+    _require_cuda(x, "x")
+    B, E = x.shape[0], x[0].numel()
+    out = torch.empty_like(x)
+    coef_c = (c_float * 4)(*(list(coef) + [0.0] * 4)[:4])
+    with torch.cuda.device(x.device):
+        check(lib.dt_cfg_update(rule, ptr(x), ptr(eps_u), ptr(eps_c), ptr(z), ptr(z_row), coef_c, int(bool(has_noise)),
+                                ptr(w), c_float(w_scalar), ptr(out), B, E, stream_ptr()), "dt_cfg_update")
+    return out
+
+
+# ---------------------------------------------------------------------- module-level forward
+def unet_forward_module(module, x, t, cond=None):
+    """General ``model(x, t, cond)`` (reference models.py:159-224): per-row t / cond with broadcasting."""
+    _require_cuda(x, "x")
+    h = UNetHandle.for_module(module)
+    B = x.shape[0]
+    t = t.reshape(t.shape[0], -1)[:, 0] if t.dim() > 1 else t
+    rows = t.shape[0]
+    c = None
+    if cond is not None:
+        c = cond.reshape(cond.shape[0], -1)[:, 0].float()
+        rows = max(rows, c.shape[0])
+    if rows not in (1, B):
+        raise RuntimeError(f"time/condition rows ({rows}) cannot broadcast onto batch {B}")
+    t_i = t.to(device=h.device, dtype=torch.int32).expand(rows).contiguous()
+    c_f = c.to(h.device).expand(rows).contiguous() if c is not None else None
+    tb = h.time_bias_general(t_i, c_f, None, rows)
+    return h.forward(x, tb, 1, B if rows == 1 else 1)
+
+
+# ---------------------------------------------------------------------- metrics
+def device_metric_sums(X, Y):
+    """float64 [B, n_max, 4] sums of dt_traj_metrics for trajectories X[nT,B,E], Y[nS,B,E] on device."""
+    lib = _hip.load()
+    _require_cuda(X, "teacher trajectory"); _require_cuda(Y, "student trajectory")
+    nT, B, E = X.shape
+    nS = Y.shape[0]
+    out = torch.empty(B, max(nT, nS), 4, dtype=torch.float64, device=X.device)
+    with torch.cuda.device(X.device):
+        check(lib.dt_traj_metrics(ptr(X), ptr(Y), nT, nS, B, E, ptr(out), stream_ptr()), "dt_traj_metrics")
+    return out
+
+
+def device_wasserstein(X, Y, index=None, index_row=None):
+    """float64 [B, n] per-step W1 over the first n = min(len) states; index int32 [tables, n, n_idx] or
+    None (all coordinates); index_row int32 [B] picks each pair's table (None: table 0)."""
+    lib = _hip.load()
+    n = min(X.shape[0], Y.shape[0])
+    _, B, E = X.shape
+    out = torch.empty(B, n, dtype=torch.float64, device=X.device)
+    n_idx = 0 if index is None else index.shape[-1]
+    with torch.cuda.device(X.device):
+        check(lib.dt_traj_wasserstein(ptr(X), ptr(Y), n, B, E, ptr(index), ptr(index_row), n_idx, ptr(out), stream_ptr()),
+              "dt_traj_wasserstein")
+    return out
+
+
+def device_resampled_distance(longer, shorter):
+    lib = _hip.load()
+    nl, B, E = longer.shape
+    ns = shorter.shape[0]
+    out = torch.empty(B, ns, dtype=torch.float64, device=longer.device)
+    with torch.cuda.device(longer.device):
+        check(lib.dt_traj_resampled_distance(ptr(longer), ptr(shorter), nl, ns, B, E, ptr(out), stream_ptr()),
+              "dt_traj_resampled_distance")
+    return out
+
+
+def metrics_from_sums(sums, w1, nT, nS, pixels, elems, resampled=None):
+    """The 25-key dict of trajectory_metrics.py:12-325 from one pair's device reductions.
+
+    sums: float64 [n_max,4] (dt_traj_metrics layout), w1: float64 [min(nT,nS)], resampled: float64
+    [min] distances of the interp1d path (unequal lengths) or None.  The host part reproduces the
+    reference's scalar arithmetic: fp32 where torch returned fp32 scalars, python floats elsewhere.
+    """
+    f32 = np.float32
+    n = min(nT, nS)
+    s32 = sums.astype(f32)                       # torch reduces in fp32 before .item()
+    D = [float(np.sqrt(s32[i, 0])) for i in range(n)]
+    Vt = [float(np.sqrt(s32[i, 1])) for i in range(1, nT)]
+    Vs = [float(np.sqrt(s32[i, 2])) for i in range(1, nS)]
+    m = {}
+    # endpoint / final-image terms use each trajectory's OWN last state (row 0, slot 3)
+    m["endpoint_distance"] = float(np.sqrt(s32[0, 3]))
+    mse = float(s32[0, 3] / f32(elems))
+    m["mse"] = mse
+    acc = 0.0
+    for i in range(n):
+        acc += float(s32[i, 0] / f32(elems))
+    m["trajectory_mse"] = np.log1p(1.0 - (acc / n) * 1000)
+    m["point_by_point_similarity"] = np.exp(-5.0 * (np.mean(D) if D else float("inf")))
+    m["log_mse_similarity"] = max(0, 1.0 - np.log1p(mse * 5000) / np.log1p(5000))
+    tl = sl = 0
+    for i in range(1, n):
+        tl += Vt[i - 1] / pixels
+        sl += Vs[i - 1] / pixels
+    tl /= (n - 1)
+    sl /= (n - 1)
+    m["teacher_path_length"], m["student_path_length"] = tl, sl
+    m["path_length_similarity"] = np.log1p(min(tl, sl) / max(tl, sl) if max(tl, sl) > 0 else 1.0)
+    te = float(np.sqrt(s32[0, 1])) / tl if tl > 0 else 0
+    se = float(np.sqrt(s32[0, 2])) / sl if sl > 0 else 0
+    m["teacher_efficiency"], m["student_efficiency"] = te, se
+    m["efficiency_similarity"] = np.log1p(min(te, se) / max(te, se) if max(te, se) > 0 else 1.0)
+    m["teacher_velocities"], m["student_velocities"] = Vt, Vs
+    vsim = [(min(a, b) / max(a, b) if max(a, b) > 0 else 1.0) for a, b in zip(Vt, Vs)]
+    m["velocity_similarities"] = vsim
+    m["mean_velocity_similarity"] = np.mean(vsim) if vsim else 0.0
+    m["position_differences"] = list(D)
+    m["mean_position_difference"] = np.mean(D) if D else 0.0
+    m["max_position_difference"] = np.max(D) if D else 0.0
+    cos, wcos = [], []
+    for i in range(n - 1):
+        vt, vs = f32(np.sqrt(s32[i + 1, 1])), f32(np.sqrt(s32[i + 1, 2]))
+        if vt > 0 and vs > 0:
+            c = float(s32[i + 1, 3] / (vt * vs))
+            cos.append(c)
+            wcos.append(c * ((float(vt) + float(vs)) / 2))
+    m["directional_consistency"] = cos
+    m["mean_directional_consistency"] = np.mean(cos) if cos else 0.0
+    if wcos:
+        total_w = sum((Vt[i] + Vs[i]) / 2 for i in range(min(len(Vt), len(Vs))))
+        m["weighted_directional_consistency"] = (sum(wcos) / total_w if total_w > 0 else 0) ** 2
+    else:
+        m["weighted_directional_consistency"] = 0.0
+    if resampled is None:
+        pd = [f32(d) for d in D]                 # numpy norms of fp32 arrays stay fp32
+    else:
+        pd = [np.float64(d) for d in resampled]
+    m["path_alignment"] = np.exp(-10.0 * np.sum(pd) / len(pd))
+    W = [np.float64(v) for v in w1]
+    m["wasserstein_distances"] = W
+    m["mean_wasserstein"] = np.mean(W)
+    m["distribution_similarity"] = np.log1p(np.exp(-m["mean_wasserstein"]))
+    return m

@@ -1,0 +1,165 @@
+/*
+ * dt_hip.h -- C ABI of libdt_hip.so, the MI355X (gfx950) implementation of the
+ * trajectory hot path of henriChevreux/distillation_trajectories.
+ *
+ * The reference is pure Python on PyTorch and defines no FFI of its own
+ * (SURVEY.md §8b); the boundary below is what a ctypes binding on the reference
+ * side would call, one entry point per reference function it replaces.  Rules:
+ *   - plain pointers and sizes only; every pointer named *_dev is a BORROWED
+ *     device pointer (e.g. torch.Tensor.data_ptr()), fp32 unless stated;
+ *   - every call takes the HIP stream to launch on (hipStream_t as void*), is
+ *     asynchronous w.r.t. the host and never synchronises;
+ *   - returns int: 0 ok, <0 argument/shape error (DT_E_*), >0 a hipError_t;
+ *   - never throws, never allocates device memory except dt_unet_create
+ *     (freed by dt_unet_destroy); scratch comes from the caller (workspace).
+ *
+ * Layouts: images are NCHW fp32 exactly as the reference holds them
+ * (x[B,C,H,W]); trajectories are step-major [n_steps][B][C*H*W].
+ */
+#ifndef DT_HIP_H
+#define DT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DT_ABI_VERSION 1
+
+enum {
+  DT_OK = 0,
+  DT_E_NULL = -1,      /* required pointer is NULL */
+  DT_E_SHAPE = -2,     /* unsupported or inconsistent shape */
+  DT_E_ARG = -3,       /* bad enum / count */
+  DT_E_WORKSPACE = -4  /* workspace too small */
+};
+
+/* cond modes of one U-Net pass: how `cond` is supplied to models.py:159 forward */
+enum { DT_COND_NONE = 0, DT_COND_ZERO = 1, DT_COND_ONE = 2 };
+
+/* update rules of the three reverse loops */
+enum {
+  DT_RULE_ENGINE = 0,  /* analysis/trajectory_engine.py:86-110  x = c1*x - c2*eps (+ sigma*z)   */
+  DT_RULE_PSAMPLE = 1, /* utils/diffusion.py:149-158            x = sra*(x - k*eps) + z*beta     */
+  DT_RULE_MANAGER = 2  /* utils/trajectory_manager.py:167-205   x = (x - 0.1*eps)/sqrt(.9) + s*z */
+};
+
+int dt_abi_version(void);
+const char *dt_status_string(int status);
+
+/* ------------------------------------------------------------------ U-Net ---
+ * Replaces models.py:85-224 DiffusionUNet (eval mode).  Weights arrive as the
+ * reference's own state_dict tensors (device pointers, native OIHW / [out,in]
+ * layouts); dt_unet_create folds BatchNorm, pads channels to multiples of 16 and
+ * re-tiles the convolution weights for the MFMA kernels into memory it owns.
+ */
+typedef struct dt_unet dt_unet;
+
+/* order of the per-block tensor pointers (8 blocks: enc1..enc4, bottleneck, dec3, dec2, dec1) */
+enum {
+  DT_BT_TIME_W = 0, DT_BT_TIME_B,
+  DT_BT_CONV1_W, DT_BT_CONV1_B, DT_BT_BN1_G, DT_BT_BN1_B, DT_BT_BN1_MEAN, DT_BT_BN1_VAR,
+  DT_BT_CONV2_W, DT_BT_CONV2_B, DT_BT_BN2_G, DT_BT_BN2_B, DT_BT_BN2_MEAN, DT_BT_BN2_VAR,
+  DT_BT_RES_W, DT_BT_RES_B, /* NULL when in_ch == out_ch (identity skip) */
+  DT_BT_COUNT
+};
+/* order of the global tensor pointers */
+enum {
+  DT_GT_TIME1_W = 0, DT_GT_TIME1_B, /* time_mlp.1 */
+  DT_GT_COND0_W, DT_GT_COND0_B,     /* cond_emb.0 */
+  DT_GT_COND2_W, DT_GT_COND2_B,     /* cond_emb.2 */
+  DT_GT_FINAL_W, DT_GT_FINAL_B,     /* final 1x1 */
+  DT_GT_FREQS,                      /* sinusoid frequencies [max(D/2,1)] (models.py:20-21) */
+  DT_GT_COUNT
+};
+
+typedef struct {
+  int32_t channels;  /* image channels C */
+  int32_t dims[4];   /* models.py:110 */
+  int32_t temb_dim;  /* models.py:101 */
+} dt_unet_desc;
+
+int dt_unet_create(const dt_unet_desc *desc,
+                   const float *const *block_tensors_dev, /* [8][DT_BT_COUNT] */
+                   const float *const *global_tensors_dev, /* [DT_GT_COUNT] */
+                   void *stream, dt_unet **out);
+void dt_unet_destroy(dt_unet *h);
+
+/* floats per row of the time-bias table (sum of padded out-channels of the 8 blocks) */
+int dt_unet_time_bias_stride(const dt_unet *h);
+
+/* models.py:175-185 + the per-block ReLU(Linear(temb)) of models.py:66-77, evaluated once per
+ * (t, cond) row instead of once per sample.  cond_dev[r] is the scalar condition of row r;
+ * cond_present_dev[r]==0 means cond=None (either array may be NULL: no cond / all present). */
+int dt_unet_time_bias(const dt_unet *h, const int32_t *t_dev, const float *cond_dev,
+                      const uint8_t *cond_present_dev, int rows, float *out_dev, void *stream);
+
+size_t dt_unet_workspace_bytes(const dt_unet *h, int batch_total, int H, int W);
+
+/* eps[n_pass*B,C,H,W] = U-Net(x[B,C,H,W]) for n_pass condition rows.  Batch row r uses time-bias
+ * row r / tb_div of tb_dev (so tb_div = B shares one (t,cond) per pass; tb_div = 1 is the fully
+ * general per-sample form of models.py:159).  x is read once and shared by all passes. */
+int dt_unet_forward(const dt_unet *h, const float *x_dev, int B, int n_pass, int H, int W,
+                    const float *tb_dev, int tb_div, float *eps_dev,
+                    void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* test hook: float offset / padded channel count of a block output inside the workspace
+ * (which: 0..7 block outputs in DT order), valid after dt_unet_forward with the same shape */
+int dt_unet_debug_activation(const dt_unet *h, int batch_total, int H, int W, int which,
+                             size_t *offset_floats, int *channels_padded, int *out_h, int *out_w);
+
+/* ------------------------------------------------------- fused CFG + update ---
+ * One reverse step for a batch: eps = e_u + w*(e_c - e_u) when eps_c_dev != NULL (else eps = e_u),
+ * then the rule's x_{t-1}, written to x_out_dev (the next trajectory slot).  coef[4] by rule:
+ *   ENGINE : c1, c2, sigma, unused       (has_noise==0: x_out = x, the t==0 step)
+ *   PSAMPLE: sqrt_recip_alpha, 1-sqrt(1-acp), beta, unused
+ *   MANAGER: beta(=1-0.9), sqrt(alpha), noise_scale, unused
+ * w_dev: per-row guidance scale [B] (NULL: use w_scalar).  z row of batch row r is
+ * z_dev + (z_row_dev ? z_row_dev[r] : r) * E.   Arithmetic is un-contracted fp32 in the
+ * reference's operation order, so given equal eps the result is bit-identical to torch CPU. */
+int dt_cfg_update(int rule, const float *x_dev, const float *eps_u_dev, const float *eps_c_dev,
+                  const float *z_dev, const int32_t *z_row_dev, const float coef[4], int has_noise,
+                  const float *w_dev, float w_scalar, float *x_out_dev, int B, int E, void *stream);
+
+/* ------------------------------------------------------------ whole loop ---
+ * Replaces the loops of utils/diffusion.py:199-208, trajectory_engine.py:61-113 and
+ * trajectory_manager.py:100-112: n_steps reverse steps, everything device-resident.
+ * traj_dev[(n_steps+1)][B][E]: slot 0 must hold x_T on entry; slot i+1 receives the state after
+ * step i.  tb_dev holds n_steps*n_pass time-bias rows in (step, pass) order.  coef_host[n_steps][4],
+ * has_noise_host[n_steps], z_shift_host[n_steps] (added to the z row index at that step). */
+int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, int W, int n_steps,
+                         const float *tb_dev, const float *coef_host, const int32_t *has_noise_host,
+                         const float *z_dev, const int32_t *z_row_dev, const int64_t *z_shift_host,
+                         const float *w_dev, float w_scalar, float *traj_dev, float *eps_scratch_dev,
+                         void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------- metrics ---
+ * Replaces the reductions of analysis/metrics/trajectory_metrics.py:55-231 and
+ * analysis/metrics/time_dependent.py:46-82.  Trajectories are [n][B][E].
+ * out_sums_dev[B][n_max][4] (float64), n_max = max(nT, nS):
+ *   i >= 1: { |X_i-Y_i|^2, |X_i-X_{i-1}|^2, |Y_i-Y_{i-1}|^2, <X_i-X_{i-1}, Y_i-Y_{i-1}> }
+ *   i == 0: { |X_0-Y_0|^2, |X_last-X_0|^2, |Y_last-Y_0|^2, |X_last-Y_last|^2 }  (own last states)
+ * terms that need a state beyond a trajectory's own length are 0.  The reference's norms run over
+ * the whole [B,C,H,W] list entry: for a batched entry call with B=1 and E=B*C*H*W (same memory). */
+int dt_traj_metrics(const float *teacher_dev, const float *student_dev, int nT, int nS, int B, int E,
+                    double *out_sums_dev, void *stream);
+
+/* trajectory_metrics.py:295-315: W1 between the (sub-sampled) value distributions of X_i and Y_i,
+ * = mean |sort(u) - sort(v)| accumulated in float64.  index_dev: [n_tables][n][n_idx] int32 coordinates
+ * to sample (NULL: use all E coordinates, requires E <= 4096); pair b uses table index_row_dev[b]
+ * (NULL: table 0) -- the reference's indices depend on the sample seed only.  out_w1_dev[B][n] float64. */
+int dt_traj_wasserstein(const float *teacher_dev, const float *student_dev, int n, int B, int E,
+                        const int32_t *index_dev, const int32_t *index_row_dev, int n_idx,
+                        double *out_w1_dev, void *stream);
+
+/* trajectory_metrics.py:239-279: linear (scipy interp1d, float64) resampling of the longer trajectory
+ * onto the shorter's normalised time grid, then |L'(t_i) - S_i|_2 in float64.  out_dist_dev[B][n_short] */
+int dt_traj_resampled_distance(const float *long_dev, const float *short_dev, int n_long, int n_short,
+                               int B, int E, double *out_dist_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DT_HIP_H */
