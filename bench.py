@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: trajectory-timesteps/sec (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): teacher (size_factor 1.0) vs student (size_factor 0.5), 16x16x3,
+T=50, batch 256, guidance scale 1.0 through the CFG sampler of utils/diffusion.py (p_sample_loop: two
+U-Net passes per step, cond=ones and cond=None, then the DDPM update), followed by the trajectory
+metrics of the 256 (teacher, student) pairs.  One "step" of this benchmark is one such pass:
+2 models x 256 samples x 50 timesteps = 25,600 trajectory-timesteps per GPU.
+
+Inputs (start noise x_T and the per-step Gaussian noise, shared by teacher and student) are synthetic,
+seeded, and resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), samples
+sharded across ranks, no data-path collective; the only exchange is one RCCL all-gather of the
+per-sample metric tensor at the end of each step (weak scaling: 256 samples per GPU).
+
+Prints ONE JSON line on rank 0 (contract in the task description), with a ``roofline`` object for the
+dominant kernel (HIP-event timed inside this process) and a ``cpu_baseline`` object (the oracle's
+restatement of the same loop timed on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+T, BATCH, H, C = 50, 256, 16, 3
+TEACHER_SF, STUDENT_SF = 1.0, 0.5
+GUIDANCE = 1.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (default: the configs[1] batch)")
+    return ap.parse_args()
+
+
+class Workload:
+    """Device-resident state of one rank's share of the benchmark."""
+
+    def __init__(self, device, rank, batch):
+        from distillation_trajectories_amd import engine
+        from distillation_trajectories_amd._hip import COND_NONE, COND_ONE
+        from distillation_trajectories_amd.config import Config
+        from distillation_trajectories_amd.models import DiffusionUNet
+        from distillation_trajectories_amd.synthetic import make_model
+        from distillation_trajectories_amd.utils.diffusion import (get_diffusion_params, psample_coefficients,
+                                                                   timestep_indices)
+        self.engine, self.device, self.B = engine, device, batch
+        cfg = Config()
+        cfg.image_size, cfg.timesteps, cfg.sample_steps = H, T, T
+        self.models = [make_model(DiffusionUNet, cfg, sf).to(device) for sf in (TEACHER_SF, STUDENT_SF)]
+        self.handles = [engine.UNetHandle.for_module(m) for m in self.models]
+        self.E = C * H * H
+        idx = timestep_indices(T, T)
+        self.coef = psample_coefficients(get_diffusion_params(T, cfg), idx)
+        self.has_noise = [i > 0 for i in idx]
+        g = torch.Generator().manual_seed(1234 + rank)          # torch CPU generator, like the reference's CPU mode
+        x_T = torch.randn(batch, self.E, generator=g)
+        z = torch.randn(sum(self.has_noise) * batch, self.E, generator=g)
+        self.x_T, self.z = x_T.to(device), z.to(device)
+        self.z_shift, k = [], 0
+        for flag in self.has_noise:
+            self.z_shift.append(k * batch)
+            k += int(flag)
+        self.tb = [h.time_bias([i for i in idx for _ in (0, 1)], [COND_NONE, COND_ONE] * T) for h in self.handles]
+        self.traj = [torch.empty(T + 1, batch, self.E, device=device) for _ in self.handles]
+        for h in self.handles:
+            h.workspace(2 * batch, H, H)
+        self.flops_per_unit = None
+
+    def step(self, world, counts):
+        """One pass of the hot path: both samplers, the metric reductions, the metric all-gather."""
+        from distillation_trajectories_amd._hip import RULE_PSAMPLE
+        from distillation_trajectories_amd.grid import all_gather_rows
+        eng = self.engine
+        for h, tb, traj in zip(self.handles, self.tb, self.traj):
+            traj[0].copy_(self.x_T)
+            h.sample(RULE_PSAMPLE, traj, H, H, tb, 2, self.coef, self.has_noise, z=self.z, z_shift=self.z_shift,
+                     w_scalar=GUIDANCE)
+        sums = eng.device_metric_sums(self.traj[0], self.traj[1])          # [B, T+1, 4] float64
+        w1 = eng.device_wasserstein(self.traj[0], self.traj[1])            # [B, T+1]   float64
+        local = torch.cat([sums.reshape(self.B, -1), w1], dim=1)
+        full = all_gather_rows(local, counts, dim=0) if world > 1 else local
+        host = full.cpu().numpy()                                          # syncs the stream
+        n = T + 1
+        vals = eng.batch_scalar_metrics(host[:, : 4 * n].reshape(-1, n, 4), host[:, 4 * n:], H * H, self.E)
+        return vals
+
+
+def cpu_baseline(batch=256, steps=8, pairs=8):
+    """The oracle's restatement of the same loop on the host cores: p_sample_loop semantics (2 passes per
+    step) for teacher and student at ``batch`` samples over the first ``steps`` of the 50 timesteps, plus
+    the metric function on ``pairs`` pairs scaled to the batch.  Reported in the benchmark's unit."""
+    from distillation_trajectories_amd.config import Config
+    from distillation_trajectories_amd.models import DiffusionUNet
+    from distillation_trajectories_amd.synthetic import make_model
+    from oracle import metrics_ref, sampler_ref, unet_ref
+    cfg = Config()
+    cfg.image_size = H
+    threads = torch.get_num_threads()
+    params = sampler_ref.diffusion_params(T)
+    g = torch.Generator().manual_seed(1234)
+    x0 = torch.randn(batch, C, H, H, generator=g)
+    trajs, t_sample = [], 0.0
+    with torch.no_grad():
+        for sf in (TEACHER_SF, STUDENT_SF):
+            sd = make_model(DiffusionUNet, cfg, sf).state_dict()
+            fn = lambda x, t, c, sd=sd: unet_ref.unet_forward(sd, x, t, c)   # noqa: E731
+            x = x0.clone()
+            traj = [x]
+            fn(x[:2], torch.full((2,), T - 1), None)                        # warm the allocator / oneDNN primitives
+            t0 = time.perf_counter()
+            for i in range(T - 1, T - 1 - steps, -1):
+                x = sampler_ref.p_sample(fn, x, torch.full((batch,), i, dtype=torch.long), i, params, GUIDANCE,
+                                         noise=torch.randn(x.shape, generator=g))
+                traj.append(x)
+            t_sample += time.perf_counter() - t0
+            trajs.append(traj)
+    t0 = time.perf_counter()
+    for b in range(pairs):
+        metrics_ref.compute_trajectory_metrics([s[b:b + 1] for s in trajs[0]], [s[b:b + 1] for s in trajs[1]])
+    t_metric_pair = (time.perf_counter() - t0) / pairs * (T + 1) / (steps + 1)   # scaled to 51-state trajectories
+    units = 2 * batch * steps
+    # per unit: sampler time + the pair's metric time spread over its 2*T trajectory-timesteps
+    sec_per_unit = t_sample / units + t_metric_pair / (2 * T)
+    return {"value": round(1.0 / sec_per_unit, 2), "unit": "trajectory-timesteps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch-CPU restatement, {threads} threads): teacher+student p_sample loop, batch {batch}, "
+                      f"{steps} of {T} timesteps, CFG 2 passes, + metrics on {pairs} pairs scaled to T+1 states; "
+                      f"sampler {t_sample:.2f}s, metrics {t_metric_pair * 1e3:.1f} ms/pair"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist = None
+
+    from distillation_trajectories_amd import _hip
+    _hip.load()
+    wl = Workload(device, rank, args.batch)
+    counts = [args.batch] * world
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        vals = wl.step(world, counts)
+    barrier()
+    profile = not args.no_profile
+    if profile:
+        _hip.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vals = wl.step(world, counts)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernels = _hip.profile_end() if profile else {}
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    units_per_step = 2 * args.batch * T * world
+    value = units_per_step * args.steps / elapsed
+    out = {
+        "metric": "trajectory-timesteps/sec (B×T U-Net fwd) at 16×16 T=50",
+        "value": round(value, 1), "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: teacher sf=1.0 vs student sf=0.5, 16x16x3, T=50, batch 256/GPU, "
+                               "p_sample_loop CFG (2 U-Net passes/step, w=1.0) + trajectory metrics of the 256 pairs",
+                   "batch_per_gpu": args.batch, "timesteps": T, "image": [C, H, H], "guidance_scale": GUIDANCE,
+                   "unet_passes_per_step": 2, "parallelism": f"sample-sharded x{world}, RCCL all-gather of metrics"},
+        "per_gpu": round(value / world, 1),
+        "metric_check": {"mean_endpoint_distance": float(np.mean(vals["endpoint_distance"])),
+                         "mean_wasserstein": float(np.mean(vals["mean_wasserstein"])),
+                         "pairs": int(len(vals["mse"]))},
+    }
+    if kernels:
+        dom_name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+        total_ms = sum(k["ms"] for k in kernels.values())
+        conv = {n: k for n, k in kernels.items() if n.startswith("conv_gemm")}
+        conv_ms, conv_fl = sum(k["ms"] for k in conv.values()), sum(k["flops"] for k in conv.values())
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
+                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "traffic": None, "launches": dom["launches"],
+                           "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
+                           "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+                           "share_of_kernel_time": round(dom["ms"] / total_ms, 3),
+                           "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
+        out["kernels"] = {n: {"launches": k["launches"], "ms": round(k["ms"], 3),
+                              "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["flops"] else None,
+                              "gbps": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["bytes"] else None}
+                          for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

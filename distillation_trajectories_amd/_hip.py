@@ -2,7 +2,8 @@
 unloadable library raises, and every non-zero status from the library raises."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_uint8,
+                    c_void_p)
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdt_hip.so")
@@ -43,6 +44,11 @@ SIGNATURES = {
     "dt_traj_wasserstein": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                     c_void_p]),
     "dt_traj_resampled_distance": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dt_profile_begin": (c_int, []),
+    "dt_profile_end": (c_int, []),
+    "dt_profile_class_count": (c_int, []),
+    "dt_profile_read": (c_int, [c_int, POINTER(c_char_p), POINTER(c_longlong), POINTER(c_double), POINTER(c_double),
+                                POINTER(c_double)]),
 }
 
 
@@ -87,3 +93,21 @@ def ptr(t):
 def stream_ptr():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_begin():
+    check(load().dt_profile_begin(), "dt_profile_begin")
+
+
+def profile_end():
+    """Stop recording and return {kernel class: dict(launches, ms, flops, bytes)} (stream must be synchronised)."""
+    lib = load()
+    check(lib.dt_profile_end(), "dt_profile_end")
+    out = {}
+    for cls in range(lib.dt_profile_class_count()):
+        name, n, ms, fl, by = c_char_p(), c_longlong(), c_double(), c_double(), c_double()
+        check(lib.dt_profile_read(cls, ctypes.byref(name), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl),
+                                  ctypes.byref(by)), "dt_profile_read")
+        if n.value:
+            out[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+    return out

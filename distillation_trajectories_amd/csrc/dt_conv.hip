@@ -160,6 +160,10 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
   const bool tall_m = blocks128 >= 256;
   const int bm = tall_m ? 128 : 64;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn);
+  // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
+  const double flops = 2.0 * p.M * (double)p.cout_real * p.cin_real * p.ksize * p.ksize;
+  ProfileScope prof(tall_m ? (wide_n ? KC_CONV_128x128 : KC_CONV_128x64) : (wide_n ? KC_CONV_64x128 : KC_CONV_64x64),
+                    flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
   if (tall_m && wide_n) conv_gemm_kernel<128, 128><<<grid, 256, 0, s>>>(p);
   else if (tall_m) conv_gemm_kernel<128, 64><<<grid, 256, 0, s>>>(p);
   else if (wide_n) conv_gemm_kernel<64, 128><<<grid, 256, 0, s>>>(p);

@@ -19,6 +19,20 @@
 
 namespace dt {
 
+// ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline numbers).
+// Off by default; when on, every instrumented launch is bracketed by two event records.
+enum KernelClass {
+  KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
+  KC_NHWC, KC_POOL, KC_UPCAT, KC_HEAD, KC_TIME_BIAS, KC_UPDATE, KC_METRICS, KC_WASSERSTEIN, KC_RESAMPLE,
+  KC_COUNT
+};
+struct ProfileScope {
+  ProfileScope(int cls, double flops, double bytes, hipStream_t s);
+  ~ProfileScope();
+  int slot;
+  hipStream_t stream;
+};
+
 constexpr int kChanPad = 16;   // activation channel granularity (= BK of the conv GEMM)
 constexpr int kNPad = 64;      // packed-weight N granularity (smallest BN tile)
 constexpr int kBlocks = 8;
@@ -38,6 +52,7 @@ struct ConvParams {
   float *out;          // [M][cout_p]
   int M, H, W;
   int cin_p, cout_p, n_p;
+  int cin_real, cout_real;  // unpadded channel counts (algorithmic flop accounting only)
   int ksize;           // 1 or 3
   int tap_lo, tap_hi;  // taps visited (a 1x1 image only sees the centre tap)
   int relu;

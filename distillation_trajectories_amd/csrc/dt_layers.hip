@@ -22,6 +22,7 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restri
 int launch_nchw_to_nhwc(const float *x, float *out, int B, int n_pass, int C, int HW, int cp, hipStream_t s) {
   const size_t total = (size_t)n_pass * B * HW * cp;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  ProfileScope prof(KC_NHWC, 0.0, 4.0 * B * C * HW * (1.0 + n_pass), s);
   nchw_to_nhwc_kernel<<<blocks, 256, 0, s>>>(x, out, B, n_pass, C, HW, cp);
   DT_LAUNCH_CHECK();
   return DT_OK;
@@ -51,6 +52,7 @@ __global__ void maxpool_kernel(const float4 *__restrict__ in, float4 *__restrict
 int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s) {
   const size_t total = (size_t)Bt * (H / 2) * (W / 2) * (cp / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  ProfileScope prof(KC_POOL, 0.0, 4.0 * Bt * H * W * cp * 1.25, s);
   maxpool_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), Bt, H, W,
                                          cp / 4);
   DT_LAUNCH_CHECK();
@@ -102,6 +104,7 @@ __global__ void upcat_kernel(const float4 *__restrict__ lo, const float4 *__rest
 int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p, hipStream_t s) {
   const size_t total = (size_t)Bt * 4 * h * w * ((c1p + c2p) / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  ProfileScope prof(KC_UPCAT, 0.0, 4.0 * Bt * h * w * (c1p + 4.0 * c2p + 4.0 * (c1p + c2p)), s);
   upcat_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(lo), reinterpret_cast<const float4 *>(skip),
                                        reinterpret_cast<float4 *>(out), Bt, h, w, c1p / 4, c2p / 4);
   DT_LAUNCH_CHECK();
@@ -150,6 +153,7 @@ int launch_head(const float *lo, const float *wf, const float *bias, float *eps,
   if (C > 4) return DT_E_SHAPE;
   const size_t n_pix = (size_t)Bt * 4 * h * w;
   const size_t blocks = (n_pix + 3) / 4;
+  ProfileScope prof(KC_HEAD, 2.0 * n_pix * C * c_real, 4.0 * (Bt * (double)h * w * c_real + n_pix * C), s);
   head_kernel<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, s>>>(lo, wf, bias, eps, Bt, h, w, cp, C, c_real);
   DT_LAUNCH_CHECK();
   return DT_OK;
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256) void time_bias_kernel(const TembWeights tw, co
 int launch_time_bias(const TembWeights &tw, const int32_t *t, const float *cond, const uint8_t *present, int rows,
                      float *out, hipStream_t s) {
   if (rows <= 0) return DT_OK;
+  ProfileScope prof(KC_TIME_BIAS, 2.0 * rows * tw.D * (2.0 * tw.D + tw.tb_stride), 4.0 * rows * tw.tb_stride, s);
   time_bias_kernel<<<rows, 256, 3 * tw.D * sizeof(float), s>>>(tw, t, cond, present, out);
   DT_LAUNCH_CHECK();
   return DT_OK;

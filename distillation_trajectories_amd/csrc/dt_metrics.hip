@@ -76,6 +76,8 @@ int launch_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, i
   if (nT < 1 || nS < 1 || B < 1 || E < 4 || E % 4) return DT_E_SHAPE;
   const int n_max = nT > nS ? nT : nS;
   if (n_max > 65535) return DT_E_SHAPE;
+  // algorithmic bytes: one read of both trajectories (2*(T+1)*E*4 per pair)
+  ProfileScope prof(KC_METRICS, 0.0, 4.0 * B * E * ((double)nT + nS), s);
   traj_metrics_kernel<<<dim3(B, n_max), 256, 0, s>>>(X, Y, nT, nS, B, E, out);
   DT_LAUNCH_CHECK();
   return DT_OK;
@@ -131,6 +133,7 @@ int launch_wasserstein(const float *X, const float *Y, int n, int B, int E, cons
   const int cnt = index ? n_idx : E;
   if (n < 1 || B < 1 || cnt < 1 || cnt > 4096 || n > 65535) return DT_E_SHAPE;
   dim3 grid(B, n);
+  ProfileScope prof(KC_WASSERSTEIN, 0.0, 8.0 * B * n * (double)cnt, s);
   if (cnt <= 1024) wasserstein_kernel<1024><<<grid, 256, 0, s>>>(X, Y, B, E, index, index_row, n_idx, out, n);
   else if (cnt <= 2048) wasserstein_kernel<2048><<<grid, 256, 0, s>>>(X, Y, B, E, index, index_row, n_idx, out, n);
   else wasserstein_kernel<4096><<<grid, 256, 0, s>>>(X, Y, B, E, index, index_row, n_idx, out, n);
@@ -177,6 +180,7 @@ int launch_resampled_distance(const float *L, const float *S, int n_long, int n_
                               hipStream_t s) {
   if (!L || !S || !out) return DT_E_NULL;
   if (n_long < 2 || n_short < 1 || n_short > n_long || B < 1 || E < 1 || n_short > 65535) return DT_E_SHAPE;
+  ProfileScope prof(KC_RESAMPLE, 0.0, 12.0 * B * E * (double)n_short, s);
   resampled_distance_kernel<<<dim3(B, n_short), 256, 0, s>>>(L, S, n_long, n_short, B, E, out);
   DT_LAUNCH_CHECK();
   return DT_OK;

@@ -25,6 +25,43 @@ int launch_resampled_distance(const float *L, const float *S, int n_long, int n_
 
 using namespace dt;
 
+// ------------------------------------------------------------------------------ profiler
+namespace {
+struct ProfRecord { hipEvent_t a, b; int cls; double flops, bytes; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRecord> rec;
+  std::vector<hipEvent_t> pool;     // events are recycled between sessions
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+} g_prof;
+const char *kClassName[KC_COUNT] = {
+    "conv_gemm_kernel<128,128>", "conv_gemm_kernel<128,64>", "conv_gemm_kernel<64,128>", "conv_gemm_kernel<64,64>",
+    "nchw_to_nhwc_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "time_bias_kernel", "cfg_update_kernel",
+    "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
+}  // namespace
+
+namespace dt {
+ProfileScope::ProfileScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_prof.on) return;
+  hipEvent_t a = g_prof.get(), b = g_prof.get();
+  if (!a || !b) return;
+  g_prof.rec.push_back(ProfRecord{a, b, cls, flops, bytes});
+  slot = (int)g_prof.rec.size() - 1;
+  (void)hipEventRecord(a, s);
+}
+ProfileScope::~ProfileScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof.rec[slot].b, stream);
+}
+}  // namespace dt
+
 struct BlockW {
   int cin, cout;          // real channels
   int cin_p, cout_p, n_p; // padded
@@ -91,6 +128,7 @@ int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &p
   ConvParams p{};
   p.M = Bt * h * w; p.H = h; p.W = w;
   p.cin_p = k.cin_p; p.cout_p = k.cout_p; p.n_p = k.n_p;
+  p.cin_real = k.cin; p.cout_real = k.cout;
   p.tb_stride = u->tb_stride; p.m_per_tb = h * w * tb_div;
   const float *res = in;   // identity skip (cin_p == cout_p)
   if (k.has_res) {
@@ -106,7 +144,7 @@ int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &p
   p.in = in; p.w = k.w1; p.scale = k.s1; p.shift = k.h1; p.tb = tb + k.tb_off; p.add = nullptr; p.out = ws + pl.h[j];
   int st = launch_conv(p, s);
   if (st) return st;
-  p.cin_p = k.cout_p;
+  p.cin_p = k.cout_p; p.cin_real = k.cout;
   p.in = ws + pl.h[j]; p.w = k.w2; p.scale = k.s2; p.shift = k.h2; p.tb = nullptr; p.add = res; p.out = ws + pl.o[j];
   return launch_conv(p, s);
 }
@@ -314,6 +352,34 @@ int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, i
     int st = launch_cfg_update(rule, x, eps_scratch, n_pass == 2 ? eps_scratch + slot : nullptr, z, z_row,
                                z_shift ? (long long)z_shift[i] : 0, coef + 4 * i, has_noise[i], w, w_scalar, xn, B, E, s);
     if (st) return st;
+  }
+  return DT_OK;
+}
+
+int dt_profile_begin(void) {
+  g_prof.rec.clear();
+  g_prof.used = 0;
+  g_prof.on = true;
+  return DT_OK;
+}
+
+int dt_profile_end(void) {
+  g_prof.on = false;
+  return DT_OK;
+}
+
+int dt_profile_class_count(void) { return KC_COUNT; }
+
+int dt_profile_read(int cls, const char **name, long long *launches, double *ms, double *flops, double *bytes) {
+  if (cls < 0 || cls >= KC_COUNT || !launches || !ms || !flops || !bytes) return DT_E_ARG;
+  if (name) *name = kClassName[cls];
+  *launches = 0; *ms = 0; *flops = 0; *bytes = 0;
+  for (const ProfRecord &r : g_prof.rec) {
+    if (r.cls != cls) continue;
+    DT_HIP_TRY(hipEventSynchronize(r.b));
+    float t = 0.f;
+    DT_HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+    *launches += 1; *ms += t; *flops += r.flops; *bytes += r.bytes;
   }
   return DT_OK;
 }

@@ -89,6 +89,8 @@ int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec
   UpdateArgs a{x, eu, ec, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4};
   const size_t total = (size_t)B * (E / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  // algorithmic bytes: read x + read z + write x' = 3*E*4 per sample-step (+ eps reads)
+  ProfileScope prof(KC_UPDATE, 0.0, 4.0 * B * E * (2.0 + (has_noise ? 1.0 : 0.0) + (ec ? 2.0 : 1.0)), s);
   switch (rule) {
     case DT_RULE_ENGINE: cfg_update_kernel<DT_RULE_ENGINE><<<blocks, 256, 0, s>>>(a); break;
     case DT_RULE_PSAMPLE: cfg_update_kernel<DT_RULE_PSAMPLE><<<blocks, 256, 0, s>>>(a); break;

@@ -297,3 +297,76 @@ def metrics_from_sums(sums, w1, nT, nS, pixels, elems, resampled=None):
     m["mean_wasserstein"] = np.mean(W)
     m["distribution_similarity"] = np.log1p(np.exp(-m["mean_wasserstein"]))
     return m
+
+
+SCALAR_KEYS = ("endpoint_distance", "mse", "trajectory_mse", "point_by_point_similarity", "log_mse_similarity",
+               "teacher_path_length", "student_path_length", "path_length_similarity", "teacher_efficiency",
+               "student_efficiency", "efficiency_similarity", "mean_velocity_similarity", "mean_position_difference",
+               "max_position_difference", "mean_directional_consistency", "weighted_directional_consistency",
+               "path_alignment", "mean_wasserstein", "distribution_similarity")
+
+
+def batch_scalar_metrics(sums, w1, pixels, elems):
+    """Vectorised form of ``metrics_from_sums`` for B equal-length pairs: {key: float64 array [B]} for the 19
+    scalar metrics (the per-step lists stay on the caller's side as sums / w1).
+
+    sums float64 [B,n,4], w1 float64 [B,n].  Follows the same dtype path (fp32 where torch returned fp32
+    scalars, float64 python arithmetic elsewhere, sequential accumulation where the reference loops)."""
+    f32 = np.float32
+    B, n, _ = sums.shape
+    with np.errstate(invalid="ignore", divide="ignore"):
+        s32 = sums.astype(f32)
+        D = np.sqrt(s32[:, :, 0]).astype(np.float64)              # [B,n]
+        Vt = np.sqrt(s32[:, 1:, 1]).astype(np.float64)            # [B,n-1]
+        Vs = np.sqrt(s32[:, 1:, 2]).astype(np.float64)
+        out = {}
+        out["endpoint_distance"] = np.sqrt(s32[:, 0, 3]).astype(np.float64)
+        mse = (s32[:, 0, 3] / f32(elems)).astype(np.float64)
+        out["mse"] = mse
+        step_mse = (s32[:, :, 0] / f32(elems)).astype(np.float64)
+        acc = np.zeros(B)
+        for i in range(n):
+            acc = acc + step_mse[:, i]
+        out["trajectory_mse"] = np.log1p(1.0 - (acc / n) * 1000)
+        meanD = D.mean(axis=1)
+        out["point_by_point_similarity"] = np.exp(-5.0 * meanD)
+        lms = 1.0 - np.log1p(mse * 5000) / np.log1p(5000)
+        out["log_mse_similarity"] = np.where(lms > 0, lms, 0.0)      # python max(0, x): NaN -> 0
+        tl, sl = np.zeros(B), np.zeros(B)
+        for i in range(n - 1):
+            tl = tl + Vt[:, i] / pixels
+            sl = sl + Vs[:, i] / pixels
+        tl, sl = tl / (n - 1), sl / (n - 1)
+        out["teacher_path_length"], out["student_path_length"] = tl, sl
+        hi = np.maximum(tl, sl)
+        out["path_length_similarity"] = np.log1p(np.where(hi > 0, np.minimum(tl, sl) / np.where(hi > 0, hi, 1), 1.0))
+        te = np.where(tl > 0, np.sqrt(s32[:, 0, 1]).astype(np.float64) / np.where(tl > 0, tl, 1), 0.0)
+        se = np.where(sl > 0, np.sqrt(s32[:, 0, 2]).astype(np.float64) / np.where(sl > 0, sl, 1), 0.0)
+        out["teacher_efficiency"], out["student_efficiency"] = te, se
+        hi = np.maximum(te, se)
+        out["efficiency_similarity"] = np.log1p(np.where(hi > 0, np.minimum(te, se) / np.where(hi > 0, hi, 1), 1.0))
+        vhi = np.maximum(Vt, Vs)
+        vsim = np.where(vhi > 0, np.minimum(Vt, Vs) / np.where(vhi > 0, vhi, 1), 1.0)
+        out["mean_velocity_similarity"] = vsim.mean(axis=1) if n > 1 else np.zeros(B)
+        out["mean_position_difference"] = meanD
+        out["max_position_difference"] = D.max(axis=1)
+        vt32, vs32 = np.sqrt(s32[:, 1:, 1]), np.sqrt(s32[:, 1:, 2])
+        ok = (vt32 > 0) & (vs32 > 0)
+        cos = np.where(ok, (s32[:, 1:, 3] / np.where(ok, vt32 * vs32, f32(1))).astype(np.float64), 0.0)
+        cnt = ok.sum(axis=1)
+        csum = np.zeros(B)
+        wsum = np.zeros(B)
+        for i in range(n - 1):
+            csum = csum + cos[:, i]
+            wsum = wsum + cos[:, i] * ((Vt[:, i] + Vs[:, i]) / 2) * ok[:, i]
+        out["mean_directional_consistency"] = np.where(cnt > 0, csum / np.where(cnt > 0, cnt, 1), 0.0)
+        tw = np.zeros(B)
+        for i in range(n - 1):
+            tw = tw + (Vt[:, i] + Vs[:, i]) / 2
+        out["weighted_directional_consistency"] = np.where(cnt > 0, np.where(tw > 0, wsum / np.where(tw > 0, tw, 1), 0.0) ** 2, 0.0)
+        pd32 = np.sqrt(s32[:, :, 0])                                # numpy norms of fp32 arrays stay fp32
+        out["path_alignment"] = np.exp(-10.0 * pd32.sum(axis=1, dtype=f32) / n).astype(np.float64)
+        mw = w1.mean(axis=1)
+        out["mean_wasserstein"] = mw
+        out["distribution_similarity"] = np.log1p(np.exp(-mw))
+    return out

@@ -159,6 +159,17 @@ int dt_traj_wasserstein(const float *teacher_dev, const float *student_dev, int 
 int dt_traj_resampled_distance(const float *long_dev, const float *short_dev, int n_long, int n_short,
                                int B, int E, double *out_dist_dev, void *stream);
 
+/* -------------------------------------------------------------- profiling ---
+ * Optional per-launch timing for the benchmark's roofline line: between dt_profile_begin() and
+ * dt_profile_end() every kernel launch of this library is bracketed by two hipEventRecord calls on
+ * the launch stream.  dt_profile_read (after the stream has been synchronised) sums, per kernel
+ * class, the launches, the event-measured milliseconds and the ALGORITHMIC flops / bytes of those
+ * launches (real channel counts, no padding; what the reference's own ops would count). */
+int dt_profile_begin(void);
+int dt_profile_end(void);
+int dt_profile_class_count(void);
+int dt_profile_read(int cls, const char **name, long long *launches, double *ms, double *flops, double *bytes);
+
 #ifdef __cplusplus
 }
 #endif
