@@ -78,7 +78,7 @@ class Workload:
         self.traj = [torch.empty(T + 1, batch, self.E, device=device) for _ in self.handles]
         for h in self.handles:
             h.workspace(2 * batch, H, H)
-        self.flops_per_unit = None
+        self.choices = None
 
     def step(self, world, counts):
         """One pass of the hot path: both samplers, the metric reductions, the metric all-gather."""
@@ -96,6 +96,9 @@ class Workload:
         host = full.cpu().numpy()                                          # syncs the stream
         n = T + 1
         vals = eng.batch_scalar_metrics(host[:, : 4 * n].reshape(-1, n, 4), host[:, 4 * n:], H * H, self.E)
+        if self.choices is None:
+            self.choices = {f"sf={sf}": [list(c) for c in h.conv_choices(2 * self.B, H, H)]
+                            for sf, h in zip((TEACHER_SF, STUDENT_SF), self.handles)}
         return vals
 
 
@@ -169,20 +172,31 @@ def main():
 
     for _ in range(args.warmup):
         vals = wl.step(world, counts)
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, no instrumentation
     barrier()
-    profile = not args.no_profile
-    if profile:
-        _hip.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         vals = wl.step(world, counts)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernels = _hip.profile_end() if profile else {}
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # ---- the same K steps again with every launch bracketed by HIP events on the launch stream
+    # (per-kernel durations for the roofline line; the ~2 event records per launch cost wall time,
+    # so this pass is kept out of `value` and its own wall time is reported beside it)
+    kernels, profiled_elapsed = {}, None
+    if not args.no_profile and rank == 0:
+        _hip.profile_begin()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step(1, [args.batch])
+        torch.cuda.synchronize()
+        profiled_elapsed = time.perf_counter() - t1
+        kernels = _hip.profile_end()
+    if dist is not None:
+        dist.barrier()
 
     units_per_step = 2 * args.batch * T * world
     value = units_per_step * args.steps / elapsed
@@ -212,7 +226,12 @@ def main():
                            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                            "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                            "share_of_kernel_time": round(dom["ms"] / total_ms, 3),
-                           "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2)}
+                           "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                           "all_conv_frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "timed_with": f"hipEventRecord pairs around every launch, second pass of the same {args.steps} "
+                                         f"steps ({profiled_elapsed / args.steps * 1e3:.1f} ms/step with events vs "
+                                         f"{elapsed / args.steps * 1e3:.1f} ms/step in the timed region)"}
+        out["tile_choices"] = wl.choices
         out["kernels"] = {n: {"launches": k["launches"], "ms": round(k["ms"], 3),
                               "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["flops"] else None,
                               "gbps": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["bytes"] else None}

@@ -33,6 +33,9 @@ SIGNATURES = {
     "dt_unet_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "dt_unet_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),
+    "dt_unet_autotune": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dt_unet_conv_choice": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
+                                    POINTER(c_int), POINTER(c_int)]),
     "dt_unet_debug_activation": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_int),
                                          POINTER(c_int), POINTER(c_int)]),
     "dt_cfg_update": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_int,

@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain dwordx4 loads, always promoted to VGPRs
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
   constexpr int WN = 2;                         // 2x2 waves
   constexpr int MI = BM / 64, NI = BN / 64;     // 32x32 MFMA tiles per wave in m / n
   constexpr int A_PER = BM / 64, B_PER = BN / 64;  // float4 staged per thread
@@ -74,8 +74,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
   // Software pipeline, one barrier per chunk: iteration `it` issues the global loads of chunk it+1
   // into registers, runs the MFMAs of chunk it from LDS stage it&1, then parks the registers in the
   // other stage.  it == -1 is the prologue (loads chunk 0, no compute).
-  const int n_iter = (p.tap_hi - p.tap_lo) * CC;
-  int tap = p.tap_lo, cc = 0;
+  const int taps_per = (p.tap_hi - p.tap_lo) / p.splits;
+  const int n_iter = taps_per * CC;
+  int tap = p.tap_lo + blockIdx.z * taps_per, cc = 0;
   for (int it = -1; it < n_iter; ++it) {
     const bool more = it + 1 < n_iter;
     f32x4 ra[A_PER], rb[B_PER];
@@ -125,12 +126,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
+  // ---- split-K: park the raw partial sums; splitk_epilogue_kernel finishes the layer
+  if (p.splits > 1) {
+    float *slab = p.slab + (size_t)blockIdx.z * p.M * p.cout_p;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+      if (n >= p.cout_p) continue;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < p.M) slab[(size_t)m * p.cout_p + n] = acc[mi][ni][r];
+        }
+      }
+    }
+    return;
+  }
+
   // ---- epilogue: folded BN, ReLU, time bias, residual; one 128-B channel run per (register, half)
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
     if (n >= p.cout_p) continue;
     const float sc = p.scale[n], sh = p.shift[n];
+    float4 w3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.x3) w3 = *reinterpret_cast<const float4 *>(p.w3 + 4 * n);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
@@ -143,31 +166,98 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (p.tb) v += p.tb[(size_t)(m / p.m_per_tb) * p.tb_stride + n];
         const size_t o = (size_t)m * p.cout_p + n;
         if (p.add) v += p.add[o];
+        if (p.x3) {
+          const float *xr = p.x3 + (size_t)m * p.x3_stride;
+          float rs = w3.w;
+          rs = fmaf(xr[0], w3.x, rs);
+          if (p.x3_c > 1) rs = fmaf(xr[p.x3_step], w3.y, rs);
+          if (p.x3_c > 2) rs = fmaf(xr[2 * p.x3_step], w3.z, rs);
+          v += rs;
+        }
         p.out[o] = v;
       }
     }
   }
 }
 
+int launch_splitk_epilogue(const ConvParams &p, hipStream_t s);
+
 int launch_conv(const ConvParams &p, hipStream_t s) {
   if (!p.in || !p.w || !p.scale || !p.shift || !p.out) return DT_E_NULL;
   if (p.cin_p % 16 || p.cout_p % 16 || p.n_p % kNPad || p.M <= 0) return DT_E_SHAPE;
   if ((long long)p.M * p.cin_p >= (1ll << 31) || (long long)p.M * p.cout_p >= (1ll << 31)) return DT_E_SHAPE;
-  const bool wide_n = p.n_p % 128 == 0;
-  const int bn = wide_n ? 128 : 64;
-  // prefer the 128-row tile once it still yields at least one workgroup per CU
-  const long long blocks128 = (long long)((p.M + 127) / 128) * (p.n_p / bn);
-  const bool tall_m = blocks128 >= 256;
-  const int bm = tall_m ? 128 : 64;
-  dim3 grid((p.M + bm - 1) / bm, p.n_p / bn);
+  int bm = p.bm, bn = p.bn;
+  if (!bm || !bn) {
+    const ConvChoice c = heuristic_choice(p.M, p.n_p, 1);
+    bm = c.bm; bn = c.bn;
+  }
+  if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128) || p.n_p % bn) return DT_E_ARG;
+  const bool tall_m = bm == 128, wide_n = bn == 128;
+  dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
+  if (p.splits < 1 || (p.tap_hi - p.tap_lo) % p.splits || (p.splits > 1 && !p.slab)) return DT_E_ARG;
   // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
   const double flops = 2.0 * p.M * (double)p.cout_real * p.cin_real * p.ksize * p.ksize;
-  ProfileScope prof(tall_m ? (wide_n ? KC_CONV_128x128 : KC_CONV_128x64) : (wide_n ? KC_CONV_64x128 : KC_CONV_64x64),
-                    flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
-  if (tall_m && wide_n) conv_gemm_kernel<128, 128><<<grid, 256, 0, s>>>(p);
-  else if (tall_m) conv_gemm_kernel<128, 64><<<grid, 256, 0, s>>>(p);
-  else if (wide_n) conv_gemm_kernel<64, 128><<<grid, 256, 0, s>>>(p);
-  else conv_gemm_kernel<64, 64><<<grid, 256, 0, s>>>(p);
+  {
+    ProfileScope prof(tall_m ? (wide_n ? KC_CONV_128x128 : KC_CONV_128x64) : (wide_n ? KC_CONV_64x128 : KC_CONV_64x64),
+                      flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
+    if (tall_m && wide_n) conv_gemm_kernel<128, 128><<<grid, 256, 0, s>>>(p);
+    else if (tall_m) conv_gemm_kernel<128, 64><<<grid, 256, 0, s>>>(p);
+    else if (wide_n) conv_gemm_kernel<64, 128><<<grid, 256, 0, s>>>(p);
+    else conv_gemm_kernel<64, 64><<<grid, 256, 0, s>>>(p);
+    DT_LAUNCH_CHECK();
+  }
+  if (p.splits > 1) return launch_splitk_epilogue(p, s);
+  return DT_OK;
+}
+
+// Default tile + tap-split choice when a layer shape has not been autotuned: the widest N tile the
+// padded channel count allows, 128 rows once that still gives two workgroups per CU, and tap groups
+// so that small spatial levels (M = batch*4*4, batch*2*2 rows) still put >= 1.5 workgroups on every CU.
+ConvChoice heuristic_choice(int M, int n_p, int taps) {
+  ConvChoice c;
+  c.bn = n_p % 128 == 0 ? 128 : 64;
+  const long long blocks128 = (long long)((M + 127) / 128) * (n_p / c.bn);
+  c.bm = blocks128 >= 512 ? 128 : 64;
+  const long long blocks = (long long)((M + c.bm - 1) / c.bm) * (n_p / c.bn);
+  c.splits = 1;
+  if (taps == 9 && M <= kSplitMaxRows && blocks < 384) c.splits = blocks * 3 >= 384 ? 3 : 9;
+  return c;
+}
+
+// sum of the split-K slabs in z order + the layer epilogue, float4 over channels
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p) {
+  const int c4 = p.cout_p >> 2;
+  const size_t total = (size_t)p.M * c4;
+  const size_t slab_stride = (size_t)p.M * p.cout_p;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % c4) * 4;
+    const size_t m = i / c4;
+    const size_t o = m * p.cout_p + n;
+    float4 a = *reinterpret_cast<const float4 *>(p.slab + o);
+    for (int z = 1; z < p.splits; ++z) {
+      const float4 b = *reinterpret_cast<const float4 *>(p.slab + z * slab_stride + o);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n), sh = *reinterpret_cast<const float4 *>(p.shift + n);
+    float4 v = make_float4(a.x * sc.x + sh.x, a.y * sc.y + sh.y, a.z * sc.z + sh.z, a.w * sc.w + sh.w);
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (p.tb) {
+      const float4 t = *reinterpret_cast<const float4 *>(p.tb + (m / p.m_per_tb) * p.tb_stride + n);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (p.add) {
+      const float4 t = *reinterpret_cast<const float4 *>(p.add + o);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    *reinterpret_cast<float4 *>(p.out + o) = v;
+  }
+}
+
+int launch_splitk_epilogue(const ConvParams &p, hipStream_t s) {
+  const size_t total = (size_t)p.M * (p.cout_p / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  ProfileScope prof(KC_SPLITK_EPILOGUE, 0.0, 4.0 * p.M * p.cout_p * (p.splits + 1.0), s);
+  splitk_epilogue_kernel<<<blocks, 256, 0, s>>>(p);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -230,6 +320,27 @@ __global__ void fold_bn_kernel(const float *cb, const float *g, const float *b, 
 int launch_fold_bn(const float *cb, const float *g, const float *b, const float *mean, const float *var, float *scale,
                    float *shift, int cout, int n_p, hipStream_t s) {
   fold_bn_kernel<<<(n_p + 255) / 256, 256, 0, s>>>(cb, g, b, mean, var, scale, shift, cout, n_p);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// enc1 skip weights [cout][C][1][1] + bias -> w3[n_p][4] = (w0, w1, w2, bias), zero on padding
+__global__ void pack_res3_kernel(const float *w, const float *b, float *w3, int cout, int C, int n_p) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_p) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < cout) {
+    v.x = w[n * C];
+    if (C > 1) v.y = w[n * C + 1];
+    if (C > 2) v.z = w[n * C + 2];
+    v.w = b[n];
+  }
+  *reinterpret_cast<float4 *>(w3 + 4 * n) = v;
+}
+
+int launch_pack_res3(const float *w, const float *b, float *w3, int cout, int C, int n_p, hipStream_t s) {
+  if (C > 3) return DT_E_SHAPE;
+  pack_res3_kernel<<<(n_p + 255) / 256, 256, 0, s>>>(w, b, w3, cout, C, n_p);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

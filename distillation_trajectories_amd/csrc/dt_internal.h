@@ -23,7 +23,8 @@ namespace dt {
 // Off by default; when on, every instrumented launch is bracketed by two event records.
 enum KernelClass {
   KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
-  KC_NHWC, KC_POOL, KC_UPCAT, KC_HEAD, KC_TIME_BIAS, KC_UPDATE, KC_METRICS, KC_WASSERSTEIN, KC_RESAMPLE,
+  KC_SPLITK_EPILOGUE, KC_IM2COL, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
+  KC_WASSERSTEIN, KC_RESAMPLE,
   KC_COUNT
 };
 struct ProfileScope {
@@ -58,9 +59,22 @@ struct ConvParams {
   int relu;
   int tb_stride;       // floats between time-bias rows
   int m_per_tb;        // GEMM rows sharing one time-bias row
+  // split-K over taps: grid.z = splits, each z walks (tap_hi-tap_lo)/splits taps and stores its raw
+  // accumulators to slab[z][M][cout_p]; splitk_epilogue then sums the slabs in z order (deterministic)
+  int splits;
+  float *slab;
+  int bm, bn;          // tile override (0 = pick by heuristic); bn = 128 needs n_p % 128 == 0
+  // enc1's 1x1 skip of the C<=4 channel image, recomputed in the epilogue instead of being
+  // materialised: add = sum_c x3[m*x3_stride + c*x3_step] * w3[n*4+c] + w3[n*4+3]
+  const float *x3;
+  const float *w3;
+  int x3_stride, x3_step, x3_c;
 };
 
 int launch_conv(const ConvParams &p, hipStream_t s);
+struct ConvChoice { int bm, bn, splits; };
+ConvChoice heuristic_choice(int M, int n_p, int taps);
+constexpr int kSplitMaxRows = 32768;   // split-K candidates only below this many GEMM rows (bounds the slab)
 
 int launch_pack_conv(const float *w_oihw, float *wp, int cout, int cin, int ksize, int cin_p, int n_p,
                      int split_c, int split_cp, hipStream_t s);
@@ -69,11 +83,12 @@ int launch_fold_bn(const float *conv_b, const float *g, const float *b, const fl
 int launch_pack_linear_rows(const float *w, const float *b, float *wp, float *bp, int out, int in, int out_p,
                             hipStream_t s);
 
-int launch_nchw_to_nhwc(const float *x, float *out, int B, int n_pass, int C, int HW, int cp, hipStream_t s);
+int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, int W, int kp, hipStream_t s);
 int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s);
 int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p, hipStream_t s);
-int launch_head(const float *lo, const float *w, const float *bias, float *eps, int Bt, int h, int w_, int cp, int C,
-                int c_real, hipStream_t s);
+int launch_head(const float *lo, const float *w, const float *bias, float *lowres, float *eps, int Bt, int h, int w_,
+                int cp, int C, int c_real, hipStream_t s);
+int launch_pack_res3(const float *w, const float *b, float *w3, int cout, int C, int n_p, hipStream_t s);
 
 struct TembWeights {
   const float *freqs;  // [half]

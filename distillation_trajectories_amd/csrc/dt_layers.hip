@@ -6,24 +6,34 @@
 
 namespace dt {
 
-// x[B][C][HW] (NCHW, shared by all passes) -> out[n_pass*B][HW][cp] with zero channel padding
-__global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restrict__ out, int B, int n_pass, int C,
-                                    int HW, int cp) {
-  const size_t total = (size_t)n_pass * B * HW * cp;
+// First-layer im2col: x[B][C][H][W] (NCHW, shared by all passes) -> patches[n_pass*B*H*W][kp] with
+// k = c*9 + (ky*3+kx) (the flattened OIHW order of conv1.weight), zero padding at the image border and
+// for k >= 9C.  enc1.conv1 then runs as a 1x1 GEMM with K = kp instead of a 9-tap walk over a
+// 16-channel-padded image (K = 144), and the centre taps (k = 9c+4) double as the NHWC image.
+__global__ void im2col3_kernel(const float *__restrict__ x, float *__restrict__ out, int B, int n_pass, int C, int H,
+                               int W, int kp) {
+  const size_t total = (size_t)n_pass * B * H * W * kp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = i % cp;
-    const size_t pix = i / cp;
-    const int hw = pix % HW;
-    const int b = (pix / HW) % B;
-    out[i] = c < C ? x[((size_t)b * C + c) * HW + hw] : 0.f;
+    const int k = i % kp;
+    size_t pix = i / kp;
+    const int xx = pix % W; pix /= W;
+    const int yy = pix % H;
+    const int b = (pix / H) % B;
+    float v = 0.f;
+    if (k < 9 * C) {
+      const int c = k / 9, tap = k - 9 * c;
+      const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+      if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[(((size_t)b * C + c) * H + sy) * W + sx];
+    }
+    out[i] = v;
   }
 }
 
-int launch_nchw_to_nhwc(const float *x, float *out, int B, int n_pass, int C, int HW, int cp, hipStream_t s) {
-  const size_t total = (size_t)n_pass * B * HW * cp;
-  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  ProfileScope prof(KC_NHWC, 0.0, 4.0 * B * C * HW * (1.0 + n_pass), s);
-  nchw_to_nhwc_kernel<<<blocks, 256, 0, s>>>(x, out, B, n_pass, C, HW, cp);
+int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, int W, int kp, hipStream_t s) {
+  const size_t total = (size_t)n_pass * B * H * W * kp;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  ProfileScope prof(KC_IM2COL, 0.0, 4.0 * B * H * W * (C + (double)n_pass * kp), s);
+  im2col3_kernel<<<blocks, 256, 0, s>>>(x, out, B, n_pass, C, H, W, kp);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -111,31 +121,22 @@ int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, 
   return DT_OK;
 }
 
-// Head: eps[b][c][Y][X] = bias[c] + sum_k Wf[c][k] * bilinear_x2(lo)[b][Y][X][k]   (models.py:221-224)
-// One wave per output pixel: lanes stride the channel axis (coalesced NHWC reads), the C partial
-// dot products are reduced with __shfl_down over the 64-lane wavefront.  C <= 4.
+// Head (models.py:221-224): eps = conv1x1(bilinear_x2(d)) + bias.  Both maps are linear and the bilinear
+// weights sum to one, so eps = bilinear_x2(conv1x1(d) + bias): the 1x1 conv runs at the LOW resolution
+// (4x fewer dot products, one NHWC pixel per wave) and only C channels are upsampled.
+// Kernel 1: one wave per low-res pixel; lanes stride the channel axis (coalesced), the C partial dot
+// products are reduced with __shfl_down over the 64-lane wavefront.  lowres[b][y][x][4].
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ lo, const float *__restrict__ wf,
-                                                   const float *__restrict__ bias, float *__restrict__ eps, int Bt,
-                                                   int h, int w, int cp, int C, int c_real) {
-  const int H = 2 * h, W = 2 * w;
+                                                   const float *__restrict__ bias, float *__restrict__ lowres,
+                                                   size_t n_pix, int cp, int C, int c_real) {
   const int lane = threadIdx.x & 63;
-  const size_t n_pix = (size_t)Bt * H * W;
   const size_t wave0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
   const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t pix = wave0; pix < n_pix; pix += n_waves) {
-    const int x = pix % W;
-    const int y = (pix / W) % H;
-    const size_t b = pix / ((size_t)W * H);
-    int y0, y1, x0, x1;
-    float wy0, wy1, wx0, wx1;
-    bilinear_src(y, h, H, y0, y1, wy0, wy1);
-    bilinear_src(x, w, W, x0, x1, wx0, wx1);
-    const float *base = lo + b * h * w * cp;
-    const float *p00 = base + ((size_t)y0 * w + x0) * cp, *p01 = base + ((size_t)y0 * w + x1) * cp;
-    const float *p10 = base + ((size_t)y1 * w + x0) * cp, *p11 = base + ((size_t)y1 * w + x1) * cp;
+    const float *p = lo + pix * cp;
     float part[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = lane; k < c_real; k += 64) {
-      const float v = wy0 * (wx0 * p00[k] + wx1 * p01[k]) + wy1 * (wx0 * p10[k] + wx1 * p11[k]);
+      const float v = p[k];
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (c < C) part[c] = fmaf(wf[c * c_real + k], v, part[c]);
@@ -143,18 +144,51 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ lo,
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       for (int off = 32; off > 0; off >>= 1) part[c] += __shfl_down(part[c], off, 64);
-    if (lane == 0)
-      for (int c = 0; c < C; ++c) eps[((b * C + c) * H + y) * W + x] = part[c] + bias[c];
+    if (lane == 0) {
+      float4 o = make_float4(part[0] + bias[0], 0.f, 0.f, 0.f);
+      if (C > 1) o.y = part[1] + bias[1];
+      if (C > 2) o.z = part[2] + bias[2];
+      *reinterpret_cast<float4 *>(lowres + pix * 4) = o;
+    }
   }
 }
 
-int launch_head(const float *lo, const float *wf, const float *bias, float *eps, int Bt, int h, int w, int cp, int C,
-                int c_real, hipStream_t s) {
-  if (C > 4) return DT_E_SHAPE;
-  const size_t n_pix = (size_t)Bt * 4 * h * w;
-  const size_t blocks = (n_pix + 3) / 4;
-  ProfileScope prof(KC_HEAD, 2.0 * n_pix * C * c_real, 4.0 * (Bt * (double)h * w * c_real + n_pix * C), s);
-  head_kernel<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, s>>>(lo, wf, bias, eps, Bt, h, w, cp, C, c_real);
+// Kernel 2: eps[b][c][Y][X] (NCHW) = bilinear_x2(lowres)[b][Y][X][c], one thread per output element
+__global__ void head_upsample_kernel(const float *__restrict__ lowres, float *__restrict__ eps, int Bt, int h, int w,
+                                     int C) {
+  const int H = 2 * h, W = 2 * w;
+  const size_t total = (size_t)Bt * C * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W;
+    size_t r = i / W;
+    const int y = r % H; r /= H;
+    const int c = r % C;
+    const size_t b = r / C;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    bilinear_src(y, h, H, y0, y1, wy0, wy1);
+    bilinear_src(x, w, W, x0, x1, wx0, wx1);
+    const float *base = lowres + b * h * w * 4 + c;
+    const float v00 = base[((size_t)y0 * w + x0) * 4], v01 = base[((size_t)y0 * w + x1) * 4];
+    const float v10 = base[((size_t)y1 * w + x0) * 4], v11 = base[((size_t)y1 * w + x1) * 4];
+    eps[i] = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+  }
+}
+
+int launch_head(const float *lo, const float *wf, const float *bias, float *lowres, float *eps, int Bt, int h, int w,
+                int cp, int C, int c_real, hipStream_t s) {
+  if (C > 3) return DT_E_SHAPE;
+  const size_t n_pix = (size_t)Bt * h * w;
+  {
+    const size_t blocks = (n_pix + 3) / 4;
+    ProfileScope prof(KC_HEAD, 2.0 * n_pix * C * c_real, 4.0 * n_pix * (c_real + 4.0), s);
+    head_kernel<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, s>>>(lo, wf, bias, lowres, n_pix, cp, C, c_real);
+    DT_LAUNCH_CHECK();
+  }
+  const size_t total = n_pix * 4 * C;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  ProfileScope prof(KC_HEAD_UP, 0.0, 4.0 * n_pix * (4.0 + 4.0 * C), s);
+  head_upsample_kernel<<<blocks, 256, 0, s>>>(lowres, eps, Bt, h, w, C);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

@@ -44,8 +44,8 @@ struct Profiler {
 } g_prof;
 const char *kClassName[KC_COUNT] = {
     "conv_gemm_kernel<128,128>", "conv_gemm_kernel<128,64>", "conv_gemm_kernel<64,128>", "conv_gemm_kernel<64,64>",
-    "nchw_to_nhwc_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "time_bias_kernel", "cfg_update_kernel",
-    "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
+    "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
 namespace dt {
@@ -69,14 +69,23 @@ struct BlockW {
   bool has_res;
   float *w1, *w2, *wr;    // packed conv weights
   float *s1, *h1, *s2, *h2, *sr, *hr;  // scale/shift per conv
+  float *w3;              // enc1 only: skip weights for the in-epilogue 1x1 (n_p x 4)
   int tb_off;             // channel offset of this block in a time-bias row
 };
 
+// (tile, split) choice of the three conv slots (0 = 1x1 skip, 1 = conv1, 2 = conv2) of every block for
+// one forward shape, filled in by dt_unet_autotune; absent shapes use heuristic_choice
+struct TunedShape {
+  int Bt, H, W;
+  ConvChoice c[kBlocks][3];
+};
+
 struct dt_unet {
+  std::vector<TunedShape> tuned;
   dt_unet_desc desc;
   BlockW blk[kBlocks];
   int cp[4];              // padded dims
-  int c_in_p;             // padded image channels
+  int kp0;                // padded K of the first-layer im2col (9*C rounded up to 16)
   int tb_stride;
   float *slab;            // one device allocation holding everything below
   size_t slab_floats;
@@ -93,9 +102,10 @@ struct Bump {
 
 // activation buffers of one forward, as float offsets into the workspace
 struct Plan {
-  size_t a0;
+  size_t a0;                                   // first-layer patches [Bt*H*W][kp0]
   size_t h[kBlocks], r[kBlocks], o[kBlocks];   // conv1 out, skip out, block out
   size_t pool[4], cat[3];
+  size_t slab, lowres;                         // split-K partial sums; low-resolution head output
   size_t total;
   int H[kBlocks], W[kBlocks];                  // spatial size of each block
 };
@@ -106,7 +116,8 @@ const int kDiv[kBlocks] = {1, 2, 4, 8, 16, 8, 4, 2};
 Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
   Plan p{};
   Bump b;
-  p.a0 = b.take((size_t)Bt * H * W * u->c_in_p);
+  p.a0 = b.take((size_t)Bt * H * W * u->kp0);
+  size_t slab = 0;
   for (int j = 0; j < kBlocks; ++j) {
     const int h = H / kDiv[j], w = W / kDiv[j];
     p.H[j] = h; p.W[j] = w;
@@ -114,39 +125,81 @@ Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
     if (j >= 1 && j <= 4) p.pool[j - 1] = b.take(px * u->blk[j].cin_p);
     if (j >= 5) p.cat[j - 5] = b.take(px * u->blk[j].cin_p);
     p.h[j] = b.take(px * u->blk[j].cout_p);
-    p.r[j] = u->blk[j].has_res ? b.take(px * u->blk[j].cout_p) : 0;
+    p.r[j] = (u->blk[j].has_res && j > 0) ? b.take(px * u->blk[j].cout_p) : 0;
     p.o[j] = b.take(px * u->blk[j].cout_p);
+    if (j > 0 && !(h == 1 && w == 1) && px <= (size_t)kSplitMaxRows) {
+      const size_t need = (size_t)9 * px * u->blk[j].cout_p;    // room for the deepest tap split
+      if (need > slab) slab = need;
+    }
   }
+  p.slab = b.take(slab);
+  p.lowres = b.take((size_t)Bt * (H / 2) * (W / 2) * 4);
   p.total = b.off;
   return p;
 }
 
-int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
-              hipStream_t s) {
+const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W) {
+  for (const TunedShape &t : u->tuned)
+    if (t.Bt == Bt && t.H == H && t.W == W) return &t;
+  return nullptr;
+}
+
+// Parameters of conv slot `slot` (0 = 1x1 skip, 1 = conv1, 2 = conv2) of block j; returns false when the
+// block has no such launch (identity skips, and enc1 whose skip is recomputed in conv2's epilogue).
+bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, const Plan &pl, int Bt, const float *tb,
+               int tb_div, const ConvChoice *choice, ConvParams &p) {
   const BlockW &k = u->blk[j];
   const int h = pl.H[j], w = pl.W[j];
-  ConvParams p{};
+  const bool dot = h == 1 && w == 1;   // a 1x1 image only ever sees the centre tap of a padded 3x3 kernel
+  p = ConvParams{};
   p.M = Bt * h * w; p.H = h; p.W = w;
   p.cin_p = k.cin_p; p.cout_p = k.cout_p; p.n_p = k.n_p;
   p.cin_real = k.cin; p.cout_real = k.cout;
   p.tb_stride = u->tb_stride; p.m_per_tb = h * w * tb_div;
-  const float *res = in;   // identity skip (cin_p == cout_p)
-  if (k.has_res) {
-    p.in = in; p.w = k.wr; p.scale = k.sr; p.shift = k.hr; p.tb = nullptr; p.add = nullptr;
-    p.out = ws + pl.r[j]; p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1; p.relu = 0;
-    int st = launch_conv(p, s);
-    if (st) return st;
-    res = ws + pl.r[j];
+  p.slab = ws + pl.slab;
+  p.in = in;
+  int taps = 1;
+  if (slot == 0) {
+    if (!k.has_res || j == 0) return false;
+    p.w = k.wr; p.scale = k.sr; p.shift = k.hr; p.out = ws + pl.r[j];
+    p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1; p.relu = 0;
+  } else if (slot == 1) {
+    p.w = k.w1; p.scale = k.s1; p.shift = k.h1; p.tb = tb + k.tb_off; p.out = ws + pl.h[j]; p.relu = 1;
+    if (j == 0) {
+      // enc1: `in` holds the im2col patches, conv1 is a 1x1 GEMM over K = kp0
+      p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1;
+    } else {
+      p.ksize = 3; p.tap_lo = dot ? 4 : 0; p.tap_hi = dot ? 5 : 9;
+      taps = dot ? 1 : 9;
+    }
+  } else {
+    p.in = ws + pl.h[j]; p.cin_p = k.cout_p; p.cin_real = k.cout;
+    p.w = k.w2; p.scale = k.s2; p.shift = k.h2; p.out = ws + pl.o[j]; p.relu = 1;
+    p.ksize = 3; p.tap_lo = dot ? 4 : 0; p.tap_hi = dot ? 5 : 9;
+    taps = dot ? 1 : 9;
+    if (j == 0) {
+      // the C-channel skip of enc1 is recomputed in the epilogue from the patches' centre taps (k = 9c+4)
+      p.x3 = in + 4; p.w3 = k.w3; p.x3_stride = u->kp0; p.x3_step = 9; p.x3_c = u->desc.channels;
+      taps = 1;   // keeps the fused (non-split) epilogue
+    } else {
+      p.add = k.has_res ? ws + pl.r[j] : in;   // identity skip: cin_p == cout_p
+    }
   }
-  // a 1x1 image only ever sees the centre tap of a padded 3x3 kernel
-  const int lo = (h == 1 && w == 1) ? 4 : 0, hi = (h == 1 && w == 1) ? 5 : 9;
-  p.ksize = 3; p.tap_lo = lo; p.tap_hi = hi; p.relu = 1;
-  p.in = in; p.w = k.w1; p.scale = k.s1; p.shift = k.h1; p.tb = tb + k.tb_off; p.add = nullptr; p.out = ws + pl.h[j];
-  int st = launch_conv(p, s);
-  if (st) return st;
-  p.cin_p = k.cout_p; p.cin_real = k.cout;
-  p.in = ws + pl.h[j]; p.w = k.w2; p.scale = k.s2; p.shift = k.h2; p.tb = nullptr; p.add = res; p.out = ws + pl.o[j];
-  return launch_conv(p, s);
+  ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
+  if (taps != 9 || p.M > kSplitMaxRows) c.splits = 1;
+  p.bm = c.bm; p.bn = c.bn; p.splits = c.splits;
+  return true;
+}
+
+int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
+              const TunedShape *tuned, hipStream_t s) {
+  ConvParams p;
+  for (int slot = 0; slot < 3; ++slot) {
+    if (!conv_slot(u, j, slot, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][slot] : nullptr, p)) continue;
+    const int st = launch_conv(p, s);
+    if (st) return st;
+  }
+  return DT_OK;
 }
 
 int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int W, const float *tb, int tb_div,
@@ -156,7 +209,8 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
   const int Bt = B * n_pass;
   const Plan pl = make_plan(u, Bt, H, W);
   if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
-  int st = launch_nchw_to_nhwc(x, ws + pl.a0, B, n_pass, u->desc.channels, H * W, u->c_in_p, s);
+  const TunedShape *tuned = find_tuned(u, Bt, H, W);
+  int st = launch_im2col3(x, ws + pl.a0, B, n_pass, u->desc.channels, H, W, u->kp0, s);
   if (st) return st;
   const float *cur = ws + pl.a0;
   for (int j = 0; j < kBlocks; ++j) {
@@ -171,10 +225,10 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
       if (st) return st;
       cur = ws + pl.cat[j - 5];
     }
-    st = run_block(u, j, cur, ws, pl, Bt, tb, tb_div, s);
+    st = run_block(u, j, cur, ws, pl, Bt, tb, tb_div, tuned, s);
     if (st) return st;
   }
-  return launch_head(ws + pl.o[7], u->final_w, u->final_b, eps, Bt, pl.H[7], pl.W[7], u->blk[7].cout_p,
+  return launch_head(ws + pl.o[7], u->final_w, u->final_b, ws + pl.lowres, eps, Bt, pl.H[7], pl.W[7], u->blk[7].cout_p,
                      u->desc.channels, u->desc.dims[0], s);
 }
 
@@ -198,7 +252,7 @@ const char *dt_status_string(int st) {
 int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float *const *gt, void *stream,
                    dt_unet **out) {
   if (!desc || !bt || !gt || !out) return DT_E_NULL;
-  if (desc->channels < 1 || desc->channels > 4 || desc->temb_dim < 2) return DT_E_SHAPE;
+  if (desc->channels < 1 || desc->channels > 3 || desc->temb_dim < 2) return DT_E_SHAPE;
   for (int i = 0; i < 4; ++i)
     if (desc->dims[i] < 1) return DT_E_SHAPE;
   for (int i = 0; i < DT_GT_COUNT; ++i)
@@ -210,7 +264,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   const int C = desc->channels, D = desc->temb_dim;
   const int *d = desc->dims;
   for (int i = 0; i < 4; ++i) u->cp[i] = round_up(d[i], kChanPad);
-  u->c_in_p = round_up(C, kChanPad);
+  u->kp0 = round_up(9 * C, kChanPad);
   // (cin, cout) and the concat split of the eight blocks -- models.py:138-154
   const int cin[kBlocks] = {C, d[0], d[1], d[2], d[3], d[3] + d[3], d[2] + d[2], d[1] + d[1]};
   const int cout[kBlocks] = {d[0], d[1], d[2], d[3], d[3], d[2], d[1], d[0]};
@@ -227,7 +281,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
       k.split_c = up_c[j]; k.split_cp = round_up(up_c[j], kChanPad);
       k.cin_p = k.split_cp + round_up(cin[j] - up_c[j], kChanPad);
     } else {
-      k.cin_p = round_up(cin[j], kChanPad);
+      k.cin_p = j == 0 ? u->kp0 : round_up(cin[j], kChanPad);   // enc1.conv1 consumes im2col patches
       k.split_c = cin[j]; k.split_cp = k.cin_p;
     }
     k.has_res = cin[j] != cout[j];
@@ -235,9 +289,9 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
       const bool optional = t == DT_BT_RES_W || t == DT_BT_RES_B;
       if (!bt[j * DT_BT_COUNT + t] && (!optional || k.has_res)) { delete u; return DT_E_NULL; }
     }
-    o_w1[j] = bump.take((size_t)9 * k.cin_p * k.n_p);
+    o_w1[j] = bump.take((size_t)(j == 0 ? 1 : 9) * k.cin_p * k.n_p);
     o_w2[j] = bump.take((size_t)9 * k.cout_p * k.n_p);
-    o_wr[j] = k.has_res ? bump.take((size_t)k.cin_p * k.n_p) : 0;
+    o_wr[j] = k.has_res ? bump.take(j == 0 ? (size_t)4 * k.n_p : (size_t)k.cin_p * k.n_p) : 0;
     o_ss[j] = bump.take((size_t)6 * k.n_p);
     k.tb_off = tb;
     tb += k.cout_p;
@@ -262,18 +316,24 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   for (int j = 0; j < kBlocks && st == DT_OK; ++j) {
     BlockW &k = u->blk[j];
     const float *const *t = bt + j * DT_BT_COUNT;
-    k.w1 = S + o_w1[j]; k.w2 = S + o_w2[j]; k.wr = k.has_res ? S + o_wr[j] : nullptr;
+    k.w1 = S + o_w1[j]; k.w2 = S + o_w2[j];
+    k.wr = (k.has_res && j > 0) ? S + o_wr[j] : nullptr;
+    k.w3 = j == 0 ? S + o_wr[j] : nullptr;
     float *ss = S + o_ss[j];
     k.s1 = ss; k.h1 = ss + k.n_p; k.s2 = ss + 2 * k.n_p; k.h2 = ss + 3 * k.n_p; k.sr = ss + 4 * k.n_p; k.hr = ss + 5 * k.n_p;
-    st = launch_pack_conv(t[DT_BT_CONV1_W], k.w1, k.cout, k.cin, 3, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
+    if (j == 0)   // OIHW [cout][C][3][3] read as a [cout][9C] matrix: a 1x1 conv over the im2col patches
+      st = launch_pack_conv(t[DT_BT_CONV1_W], k.w1, k.cout, 9 * C, 1, k.cin_p, k.n_p, 9 * C, k.cin_p, s);
+    else
+      st = launch_pack_conv(t[DT_BT_CONV1_W], k.w1, k.cout, k.cin, 3, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
     if (!st) st = launch_pack_conv(t[DT_BT_CONV2_W], k.w2, k.cout, k.cout, 3, k.cout_p, k.n_p, k.cout, k.cout_p, s);
-    if (!st && k.has_res)
+    if (!st && k.has_res && j > 0)
       st = launch_pack_conv(t[DT_BT_RES_W], k.wr, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
+    if (!st && j == 0) st = launch_pack_res3(t[DT_BT_RES_W], t[DT_BT_RES_B], k.w3, k.cout, C, k.n_p, s);
     if (!st) st = launch_fold_bn(t[DT_BT_CONV1_B], t[DT_BT_BN1_G], t[DT_BT_BN1_B], t[DT_BT_BN1_MEAN], t[DT_BT_BN1_VAR],
                                  k.s1, k.h1, k.cout, k.n_p, s);
     if (!st) st = launch_fold_bn(t[DT_BT_CONV2_B], t[DT_BT_BN2_G], t[DT_BT_BN2_B], t[DT_BT_BN2_MEAN], t[DT_BT_BN2_VAR],
                                  k.s2, k.h2, k.cout, k.n_p, s);
-    if (!st && k.has_res)
+    if (!st && k.has_res && j > 0)
       st = launch_fold_bn(t[DT_BT_RES_B], nullptr, nullptr, nullptr, nullptr, k.sr, k.hr, k.cout, k.n_p, s);
     if (!st) st = launch_pack_linear_rows(t[DT_BT_TIME_W], t[DT_BT_TIME_B], S + o_wt + (size_t)k.tb_off * D,
                                           S + o_bt + k.tb_off, k.cout, D, k.cout_p, s);
@@ -314,6 +374,81 @@ size_t dt_unet_workspace_bytes(const dt_unet *h, int batch_total, int H, int W) 
 int dt_unet_forward(const dt_unet *h, const float *x, int B, int n_pass, int H, int W, const float *tb, int tb_div,
                     float *eps, void *ws, size_t ws_bytes, void *stream) {
   return forward_impl(h, x, B, n_pass, H, W, tb, tb_div, eps, (float *)ws, ws_bytes, (hipStream_t)stream);
+}
+
+// Times every admissible (tile, tap split) of every conv launch of one forward shape with HIP events on
+// `stream` (synchronises; call it outside hot loops and graph captures) and records the fastest.
+// Activations in the workspace are whatever the last forward left there (run one first: all-zero or
+// garbage operands would let the chip clock differently from real data).
+int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace, size_t ws_bytes, void *stream) {
+  if (!h || !workspace) return DT_E_NULL;
+  if (batch_total < 1 || H < 16 || W < 16 || H % 16 || W % 16) return DT_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const Plan pl = make_plan(h, batch_total, H, W);
+  if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
+  float *ws = (float *)workspace;
+  hipEvent_t e0, e1;
+  DT_HIP_TRY(hipEventCreate(&e0));
+  DT_HIP_TRY(hipEventCreate(&e1));
+  TunedShape t{};
+  t.Bt = batch_total; t.H = H; t.W = W;
+  const float *tb = h->slab;   // any readable floats: only timing matters here
+  int st = DT_OK;
+  for (int j = 0; j < kBlocks && st == DT_OK; ++j) {
+    const float *in = j == 0 ? ws + pl.a0 : (j <= 4 ? ws + pl.pool[j - 1] : ws + pl.cat[j - 5]);
+    for (int slot = 0; slot < 3 && st == DT_OK; ++slot) {
+      ConvParams p;
+      if (!conv_slot(h, j, slot, in, ws, pl, batch_total, tb, batch_total, nullptr, p)) continue;
+      const bool can_split = p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && !p.x3 && p.M <= kSplitMaxRows;
+      ConvChoice best{p.bm, p.bn, p.splits};
+      float best_ms = 1e30f;
+      for (int bm = 64; bm <= 128; bm += 64)
+        for (int bn = 64; bn <= 128; bn += 64) {
+          if (p.n_p % bn) continue;
+          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= 3) {
+            ConvParams q = p;
+            q.bm = bm; q.bn = bn; q.splits = sp;
+            float ms_min = 1e30f;
+            for (int rep = 0; rep < 3 && st == DT_OK; ++rep) {
+              (void)hipEventRecord(e0, s);
+              st = launch_conv(q, s);
+              (void)hipEventRecord(e1, s);
+              if (hipEventSynchronize(e1) != hipSuccess) st = (int)hipGetLastError();
+              float ms = 0.f;
+              (void)hipEventElapsedTime(&ms, e0, e1);
+              if (rep > 0 && ms < ms_min) ms_min = ms;   // first repetition warms caches / code
+            }
+            if (ms_min < best_ms) { best_ms = ms_min; best = ConvChoice{bm, bn, sp}; }
+          }
+        }
+      t.c[j][slot] = best;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (st != DT_OK) return st;
+  for (TunedShape &old : h->tuned)
+    if (old.Bt == t.Bt && old.H == t.H && old.W == t.W) { old = t; return DT_OK; }
+  h->tuned.push_back(t);
+  return DT_OK;
+}
+
+/* test / report hook: the (bm, bn, splits) in use for block j, slot (0 skip, 1 conv1, 2 conv2) at a shape */
+int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
+                        int *splits, int *tuned) {
+  if (!h || !bm || !bn || !splits || !tuned) return DT_E_NULL;
+  if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H % 16 || W % 16 || batch_total < 1) return DT_E_ARG;
+  const Plan pl = make_plan(h, batch_total, H, W);
+  const TunedShape *t = find_tuned(h, batch_total, H, W);
+  ConvParams p;
+  float dummy = 0.f;
+  if (!conv_slot(h, block, slot, &dummy, &dummy, pl, batch_total, &dummy, 1, t ? &t->c[block][slot] : nullptr, p)) {
+    *bm = *bn = *splits = 0; *tuned = 0;
+    return DT_OK;
+  }
+  if (!p.bm || !p.bn) { const ConvChoice c = heuristic_choice(p.M, p.n_p, 1); p.bm = c.bm; p.bn = c.bn; }
+  *bm = p.bm; *bn = p.bn; *splits = p.splits; *tuned = t != nullptr;
+  return DT_OK;
 }
 
 int dt_unet_debug_activation(const dt_unet *h, int batch_total, int H, int W, int which, size_t *off, int *cp,

@@ -7,6 +7,7 @@ device -- the product has no CPU path (the CPU restatement lives in oracle/ and 
 """
 import ctypes
 import math
+import os
 from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 import numpy as np
@@ -16,6 +17,7 @@ from . import _hip
 from ._hip import (COND_NONE, COND_ONE, COND_ZERO, RULE_ENGINE, RULE_MANAGER, RULE_PSAMPLE, HipLibraryError, check,
                    ptr, stream_ptr)
 
+AUTOTUNE_MIN_ROWS = 16384       # batch_total*H*W from which a forward shape is worth tuning once
 BLOCK_NAMES = ("enc1", "enc2", "enc3", "enc4", "bottleneck", "dec3", "dec2", "dec1")
 _BLOCK_KEYS = ("time_mlp.weight", "time_mlp.bias",
                "conv1.weight", "conv1.bias", "norm1.weight", "norm1.bias", "norm1.running_mean", "norm1.running_var",
@@ -65,6 +67,7 @@ class UNetHandle:
         self.h = h
         self.tb_stride = self.lib.dt_unet_time_bias_stride(self.h)
         self._ws = {}
+        self._tuned = set()
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -101,6 +104,29 @@ class UNetHandle:
             ws = self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
         return ws
 
+    def autotune(self, batch_total, H, W):
+        """Measure tile / tap-split candidates for this forward shape once and keep the fastest (dt_unet_autotune)."""
+        key = (batch_total, H, W)
+        if key in self._tuned:
+            return
+        ws = self.workspace(batch_total, H, W)
+        with torch.cuda.device(self.device):
+            check(self.lib.dt_unet_autotune(self.h, batch_total, H, W, ptr(ws), c_size_t(ws.numel()), stream_ptr()),
+                  "dt_unet_autotune")
+        self._tuned.add(key)
+
+    def conv_choices(self, batch_total, H, W):
+        """[(block, slot, bm, bn, splits, tuned)] for reporting."""
+        out = []
+        for j in range(8):
+            for slot in range(3):
+                bm, bn, sp, tu = c_int(), c_int(), c_int(), c_int()
+                check(self.lib.dt_unet_conv_choice(self.h, batch_total, H, W, j, slot, ctypes.byref(bm), ctypes.byref(bn),
+                                                   ctypes.byref(sp), ctypes.byref(tu)), "dt_unet_conv_choice")
+                if bm.value:
+                    out.append((BLOCK_NAMES[j], ("skip", "conv1", "conv2")[slot], bm.value, bn.value, sp.value, bool(tu.value)))
+        return out
+
     def time_bias(self, t_values, cond_modes):
         """[rows, tb_stride] table for rows (t_values[i], cond_modes[i]); cond mode in {NONE, ZERO, ONE}."""
         rows = len(t_values)
@@ -116,7 +142,7 @@ class UNetHandle:
                                              stream_ptr()), "dt_unet_time_bias")
         return out
 
-    def forward(self, x, tb, n_pass, tb_div):
+    def forward(self, x, tb, n_pass, tb_div, tune=None):
         """eps[n_pass*B,C,H,W] for x[B,C,H,W]; tb rows as documented in dt_hip.h."""
         _require_cuda(x, "x")
         x = x.contiguous().float()
@@ -125,10 +151,24 @@ class UNetHandle:
             raise HipLibraryError(f"x has {C} channels, the model expects {self.channels}")
         eps = torch.empty(n_pass * B, C, H, W, dtype=torch.float32, device=self.device)
         ws = self.workspace(n_pass * B, H, W)
-        with torch.cuda.device(self.device):
-            check(self.lib.dt_unet_forward(self.h, ptr(x), B, n_pass, H, W, ptr(tb), tb_div, ptr(eps), ptr(ws),
-                                           c_size_t(ws.numel()), stream_ptr()), "dt_unet_forward")
+
+        def run():
+            with torch.cuda.device(self.device):
+                check(self.lib.dt_unet_forward(self.h, ptr(x), B, n_pass, H, W, ptr(tb), tb_div, ptr(eps), ptr(ws),
+                                               c_size_t(ws.numel()), stream_ptr()), "dt_unet_forward")
+        if self._wants_tuning(n_pass * B, H, W, tune):
+            run()                                  # real activations in the workspace for the timing runs
+            self.autotune(n_pass * B, H, W)
+        run()
         return eps
+
+    def _wants_tuning(self, batch_total, H, W, tune):
+        """Autotune big shapes once (>= 16k GEMM rows at full resolution) unless DT_AUTOTUNE=0."""
+        if (batch_total, H, W) in self._tuned:
+            return False
+        if tune is None:
+            tune = os.environ.get("DT_AUTOTUNE", "1") != "0" and batch_total * H * W >= AUTOTUNE_MIN_ROWS
+        return bool(tune)
 
     def debug_activation(self, batch_total, H, W, which):
         """NHWC view [Bt,h,w,cp] of block ``which``'s output inside the workspace of the last forward."""
@@ -151,6 +191,8 @@ class UNetHandle:
         shift_c = (c_int64 * n_steps)(*[int(v) for v in (z_shift if z_shift is not None else [0] * n_steps)])
         eps = torch.empty(n_pass, B, traj.shape[2], dtype=torch.float32, device=self.device)
         ws = self.workspace(n_pass * B, H, W)
+        if n_steps and self._wants_tuning(n_pass * B, H, W, None):
+            self.forward(traj[0].reshape(B, self.channels, H, W), tb[:n_pass].contiguous(), n_pass, B, tune=True)
         with torch.cuda.device(self.device):
             check(self.lib.dt_sample_trajectory(self.h, rule, B, n_pass, H, W, n_steps, ptr(tb), coef_c, noise_c,
                                                 ptr(z), ptr(z_row), shift_c, ptr(w), c_float(w_scalar), ptr(traj),

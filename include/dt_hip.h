@@ -105,6 +105,16 @@ int dt_unet_forward(const dt_unet *h, const float *x_dev, int B, int n_pass, int
                     const float *tb_dev, int tb_div, float *eps_dev,
                     void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* Optional: measure (HIP events, synchronises the stream) every admissible tile / tap-split of every
+ * convolution launch of a forward with batch_total = n_pass*B rows and remember the fastest per layer;
+ * later dt_unet_forward / dt_sample_trajectory calls with the same (batch_total, H, W) use them.
+ * Results are identical up to fp32 summation order (the split changes the grouping of the tap sum). */
+int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace_dev, size_t workspace_bytes,
+                     void *stream);
+/* report hook: tile (bm x bn) and tap split in use for block (0..7), slot (0 skip, 1 conv1, 2 conv2) */
+int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
+                        int *splits, int *tuned);
+
 /* test hook: float offset / padded channel count of a block output inside the workspace
  * (which: 0..7 block outputs in DT order), valid after dt_unet_forward with the same shape */
 int dt_unet_debug_activation(const dt_unet *h, int batch_total, int H, int W, int which,

@@ -102,8 +102,9 @@ def test_unet_forward_odd_channel_counts(models, sf):
 
 
 def test_unet_forward_large_batch_properties(gpu_models):
-    """Full bench batch (2 passes x 256) through the 128-row tiles: rows are independent and the CFG
-    batch equals two separate single-pass calls bit for bit."""
+    """Full bench batch (2 passes x 256) through the 128-row tiles: rows are independent (bit-exact under
+    a batch permutation) and the CFG batch agrees with two separate single-pass calls (those take other
+    tile / split-K shapes, so only to fp32 re-association noise)."""
     m = gpu_models(0.5)
     h = engine.UNetHandle.for_module(m)
     x = torch.randn(256, 3, 16, 16, generator=torch.Generator().manual_seed(3)).to(DEV)
@@ -114,7 +115,8 @@ def test_unet_forward_large_batch_properties(gpu_models):
     assert torch.equal(again[:256], both[:256][perm]) and torch.equal(again[256:], both[256:][perm])
     solo_u = h.forward(x, tb[0:1].contiguous(), 1, 256)
     solo_c = h.forward(x, tb[1:2].contiguous(), 1, 256)
-    assert torch.equal(solo_u, both[:256]) and torch.equal(solo_c, both[256:])
+    assert_close(solo_u.cpu().numpy(), both[:256].cpu().numpy(), rtol=1e-5, atol=1e-6, what='solo uncond')
+    assert_close(solo_c.cpu().numpy(), both[256:].cpu().numpy(), rtol=1e-5, atol=1e-6, what='solo cond')
     # oracle spot check on 4 rows
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():
