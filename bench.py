@@ -112,7 +112,9 @@ def cpu_baseline(batch=256, steps=8, pairs=8):
     from oracle import metrics_ref, sampler_ref, unet_ref
     cfg = Config()
     cfg.image_size = H
-    threads = torch.get_num_threads()
+    prev_threads = torch.get_num_threads()
+    threads = min(16, os.cpu_count() or 1)          # the GPU box's CPU share per GPU
+    torch.set_num_threads(threads)
     params = sampler_ref.diffusion_params(T)
     g = torch.Generator().manual_seed(1234)
     x0 = torch.randn(batch, C, H, H, generator=g)
@@ -138,6 +140,7 @@ def cpu_baseline(batch=256, steps=8, pairs=8):
     units = 2 * batch * steps
     # per unit: sampler time + the pair's metric time spread over its 2*T trajectory-timesteps
     sec_per_unit = t_sample / units + t_metric_pair / (2 * T)
+    torch.set_num_threads(prev_threads)
     return {"value": round(1.0 / sec_per_unit, 2), "unit": "trajectory-timesteps/s", "cores": threads, "kind": "port",
             "sample": f"oracle (torch-CPU restatement, {threads} threads): teacher+student p_sample loop, batch {batch}, "
                       f"{steps} of {T} timesteps, CFG 2 passes, + metrics on {pairs} pairs scaled to T+1 states; "
