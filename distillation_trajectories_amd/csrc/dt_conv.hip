@@ -15,12 +15,9 @@
 // identically for A and B, so the sum over k is complete and the result layout is the standard one:
 // acc register r of lane l = D[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31], i.e. a register is a 128-B run
 // of consecutive channels for two pixel rows -> coalesced NHWC stores.
-#include "dt_internal.h"
+#include "dt_conv_epilogue.h"
 
 namespace dt {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain dwordx4 loads, always promoted to VGPRs
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
@@ -126,58 +123,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  // ---- split-K: park the raw partial sums; splitk_epilogue_kernel finishes the layer
-  if (p.splits > 1) {
-    float *slab = p.slab + (size_t)blockIdx.z * p.M * p.cout_p;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
-      if (n >= p.cout_p) continue;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < p.M) slab[(size_t)m * p.cout_p + n] = acc[mi][ni][r];
-        }
-      }
-    }
-    return;
-  }
-
-  // ---- epilogue: folded BN, ReLU, time bias, residual; one 128-B channel run per (register, half)
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
-    if (n >= p.cout_p) continue;
-    const float sc = p.scale[n], sh = p.shift[n];
-    float4 w3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.x3) w3 = *reinterpret_cast<const float4 *>(p.w3 + 4 * n);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m >= p.M) continue;
-        float v = acc[mi][ni][r] * sc + sh;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.tb) v += p.tb[(size_t)(m / p.m_per_tb) * p.tb_stride + n];
-        const size_t o = (size_t)m * p.cout_p + n;
-        if (p.add) v += p.add[o];
-        if (p.x3) {
-          const float *xr = p.x3 + (size_t)m * p.x3_stride;
-          float rs = w3.w;
-          rs = fmaf(xr[0], w3.x, rs);
-          if (p.x3_c > 1) rs = fmaf(xr[p.x3_step], w3.y, rs);
-          if (p.x3_c > 2) rs = fmaf(xr[2 * p.x3_step], w3.z, rs);
-          v += rs;
-        }
-        p.out[o] = v;
-      }
-    }
-  }
+  conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
 }
 
 int launch_splitk_epilogue(const ConvParams &p, hipStream_t s);
@@ -197,7 +143,12 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
   if (p.splits < 1 || (p.tap_hi - p.tap_lo) % p.splits || (p.splits > 1 && !p.slab)) return DT_E_ARG;
   // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
   const double flops = 2.0 * p.M * (double)p.cout_real * p.cin_real * p.ksize * p.ksize;
-  {
+  if (p.prec == 1) {
+    ProfileScope prof(tall_m ? (wide_n ? KC_CONVB_128x128 : KC_CONVB_128x64) : (wide_n ? KC_CONVB_64x128 : KC_CONVB_64x64),
+                      flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
+    const int st = launch_conv_bf16x6(p, bm, bn, s);
+    if (st) return st;
+  } else {
     ProfileScope prof(tall_m ? (wide_n ? KC_CONV_128x128 : KC_CONV_128x64) : (wide_n ? KC_CONV_64x128 : KC_CONV_64x64),
                       flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
     if (tall_m && wide_n) conv_gemm_kernel<128, 128><<<grid, 256, 0, s>>>(p);
@@ -220,6 +171,7 @@ ConvChoice heuristic_choice(int M, int n_p, int taps) {
   c.bm = blocks128 >= 512 ? 128 : 64;
   const long long blocks = (long long)((M + c.bm - 1) / c.bm) * (n_p / c.bn);
   c.splits = 1;
+  c.prec = 0;
   if (taps == 9 && M <= kSplitMaxRows && blocks < 384) c.splits = blocks * 3 >= 384 ? 3 : 9;
   return c;
 }

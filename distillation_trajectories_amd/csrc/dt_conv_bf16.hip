@@ -1,0 +1,211 @@
+// Implicit-GEMM convolution with fp32-accurate arithmetic on the bf16 matrix cores ("split-bf16").
+//
+// gfx950 has no reduced-precision fast path for fp32 inputs (no xf32/TF32); its exact fp32 MFMA runs at
+// 1/16 of the bf16 rate.  This kernel keeps fp32 ACCURACY while using v_mfma_f32_32x32x16_bf16:
+// every fp32 operand is split EXACTLY into three bf16 planes
+//      a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
+// (round-to-nearest at each step; the residuals are exact in fp32 and the third one fits in 8 bits, so
+// the three planes carry all 24 significand bits), and a*b is evaluated as the six plane products whose
+// magnitude can reach 2^-24 of |a*b|:
+//      a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1)          [dropped: a2b3, a3b2, a3b3 <= 2^-26 |ab|]
+// Each bf16 x bf16 product is exact in the fp32 accumulator, so the result differs from an exact-product
+// fp32 accumulation by < 2^-25 relative per term -- below fp32's own rounding.  Six bf16 MFMAs (6 x 32
+// cycles for 32x32x16) replace eight fp32 MFMAs (8 x 64 cycles): 2.67x fewer matrix-pipe cycles.
+//
+// Weights are split once at pack time ([K/16][3 planes][N_pad][16 k], LDS-ready).  Activations stay fp32
+// in HBM; a thread splits the 8 consecutive k it stages (2 x dwordx4 -> 3 x ds_write_b128, ~45 VALU).
+// Tiling, tap walk, split-K and epilogue are those of dt_conv.hip.  LDS: per stage 3 planes x (BM+BN) rows
+// x 32 B; the two 16-B halves of a row are swapped on rows with bit 3 set, which makes ds_read_b128's
+// 16-lane groups conflict-free (rows 32 B apart would otherwise collide two-way).
+#include "dt_conv_epilogue.h"
+
+namespace dt {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float bf16_to_f32(__bf16 v) { return (float)v; }
+
+// exact three-way split of 8 consecutive fp32 values into bf16 planes (packed 8 x bf16 = 16 B each)
+__device__ inline void split8(const f32x4 lo, const f32x4 hi, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a = i < 4 ? lo[i] : hi[i - 4];
+    const __bf16 a1 = (__bf16)a;
+    const float r1 = a - (float)a1;
+    const __bf16 a2 = (__bf16)r1;
+    const float r2 = r1 - (float)a2;
+    p1[i] = a1; p2[i] = a2; p3[i] = (__bf16)r2;
+  }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvParams p) {
+  constexpr int WN = 2;
+  constexpr int MI = BM / 64, NI = BN / 64;
+  constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;            // bf16 elements per plane per stage
+  constexpr int STAGE = 3 * (PLANE_A + PLANE_B);                  // bf16 elements per stage
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int HW = p.H * p.W;
+  const int CC = p.cin_p >> 4;
+
+  // ---- A staging: thread -> (row, k-half): 8 consecutive k = 32 contiguous bytes of one pixel
+  const bool a_thread = tid < BM * 2;
+  const int a_rowi = tid >> 1, a_hh = tid & 1;
+  const int a_m = m0 + a_rowi;
+  const bool a_ok = a_thread && a_m < p.M;
+  const int a_mm = a_ok ? a_m : 0;
+  const int a_b = a_mm / HW, a_rem = a_mm - a_b * HW;
+  const int a_y = a_rem / p.W, a_x = a_rem - a_y * p.W;
+  const int a_off = a_mm * p.cin_p + a_hh * 8;
+  const int a_lds = a_rowi * 16 + ((a_hh ^ ((a_rowi >> 3) & 1)) << 3);   // element offset inside a plane
+  // ---- B staging: the three plane tiles are contiguous [BN][16] bf16 runs in the packed weights
+  const bool b_thread = tid < BN * 2;
+  const __bf16 *wbase = reinterpret_cast<const __bf16 *>(p.w) + (size_t)n0 * 16 + tid * 8;
+  const size_t w_plane = (size_t)p.n_p * 16;                       // elements between planes of one chunk
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  int a_frag[MI], b_frag[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * (MI * 32) + mi * 32 + l31;
+    a_frag[mi] = row * 16 + ((half ^ ((row >> 3) & 1)) << 3);
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = wn * (NI * 32) + ni * 32 + l31;
+    b_frag[ni] = row * 16 + ((half ^ ((row >> 3) & 1)) << 3);
+  }
+
+  const int taps_per = (p.tap_hi - p.tap_lo) / p.splits;
+  const int n_iter = taps_per * CC;
+  int tap = p.tap_lo + blockIdx.z * taps_per, cc = 0;
+  for (int it = -1; it < n_iter; ++it) {
+    const bool more = it + 1 < n_iter;
+    f32x4 ra0 = {0.f, 0.f, 0.f, 0.f}, ra1 = ra0;
+    u32x4 rb[3];
+    if (more) {
+      int dy = 0, dx = 0;
+      if (p.ksize == 3) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+      const int yy = a_y + dy, xx = a_x + dx;
+      if (a_ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+        const float *src = p.in + a_off + (dy * p.W + dx) * p.cin_p + cc * 16;
+        ra0 = *reinterpret_cast<const f32x4 *>(src);
+        ra1 = *reinterpret_cast<const f32x4 *>(src + 4);
+      }
+      if (b_thread) {
+        const __bf16 *wt = wbase + (size_t)(tap * CC + cc) * 3 * w_plane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rb[pl] = *reinterpret_cast<const u32x4 *>(wt + pl * w_plane);
+      }
+      if (++cc == CC) { cc = 0; ++tap; }
+    }
+    if (it >= 0) {
+      const __bf16 *A = lds + (it & 1) * STAGE, *B = A + 3 * PLANE_A;
+      bf16x8 fb[NI][3];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fb[ni][pl] = *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        bf16x8 fa[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fa[pl] = *reinterpret_cast<const bf16x8 *>(A + pl * PLANE_A + a_frag[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          // smallest terms first so their sum is formed before it meets the large partial sums
+          f32x16 c = acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][0], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+      }
+    }
+    if (more) {
+      __bf16 *A = lds + ((it + 1) & 1) * STAGE, *B = A + 3 * PLANE_A;
+      if (a_thread) {
+        bf16x8 p1, p2, p3;
+        split8(ra0, ra1, p1, p2, p3);
+        *reinterpret_cast<bf16x8 *>(A + a_lds) = p1;
+        *reinterpret_cast<bf16x8 *>(A + PLANE_A + a_lds) = p2;
+        *reinterpret_cast<bf16x8 *>(A + 2 * PLANE_A + a_lds) = p3;
+      }
+      if (b_thread) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(B + pl * PLANE_B + tid * 8) = rb[pl];
+      }
+    }
+    __syncthreads();
+  }
+  conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
+}
+
+int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s) {
+  dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
+  if (bm == 128 && bn == 128) conv_gemm_bf16x6_kernel<128, 128><<<grid, 256, 0, s>>>(p);
+  else if (bm == 128) conv_gemm_bf16x6_kernel<128, 64><<<grid, 256, 0, s>>>(p);
+  else if (bn == 128) conv_gemm_bf16x6_kernel<64, 128><<<grid, 256, 0, s>>>(p);
+  else conv_gemm_bf16x6_kernel<64, 64><<<grid, 256, 0, s>>>(p);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight split + re-tiling (once per model): wp is bf16 [K/16][3][n_p][16], element k = 8*hh + j of row n
+// stored at half (hh ^ ((n>>3)&1)); k = tap*cin_p + cp with the same concat mapping as pack_conv_kernel.
+__global__ void pack_conv_bf16x3_kernel(const float *__restrict__ w, __bf16 *__restrict__ wp, int cout, int cin,
+                                        int ksize, int cin_p, int n_p, int split_c, int split_cp, size_t total) {
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    // idx enumerates (kc, n, phys position 0..15); the three planes are written together
+    const int pos = idx & 15;
+    const size_t rowi = idx >> 4;
+    const int n = rowi % n_p;
+    const size_t kc = rowi / n_p;
+    const int phh = pos >> 3, j = pos & 7;
+    const int hh = phh ^ ((n >> 3) & 1);
+    const int k = (int)kc * 16 + hh * 8 + j;
+    const int tap = k / cin_p, cp = k - tap * cin_p;
+    int c = -1;
+    if (cp < split_cp) { if (cp < split_c) c = cp; }
+    else { const int cc = split_c + (cp - split_cp); if (cc < cin) c = cc; }
+    float v = 0.f;
+    if (n < cout && c >= 0) v = w[((size_t)n * cin + c) * (ksize * ksize) + tap];
+    const __bf16 a1 = (__bf16)v;
+    const float r1 = v - (float)a1;
+    const __bf16 a2 = (__bf16)r1;
+    const __bf16 a3 = (__bf16)(r1 - (float)a2);
+    const size_t base = (kc * 3 * n_p + n) * 16 + pos;
+    const size_t plane = (size_t)n_p * 16;
+    wp[base] = a1; wp[base + plane] = a2; wp[base + 2 * plane] = a3;
+  }
+}
+
+int launch_pack_conv_bf16x3(const float *w, void *wp, int cout, int cin, int ksize, int cin_p, int n_p, int split_c,
+                            int split_cp, hipStream_t s) {
+  const size_t total = (size_t)ksize * ksize * cin_p * n_p;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  pack_conv_bf16x3_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<__bf16 *>(wp), cout, cin, ksize, cin_p, n_p,
+                                                 split_c, split_cp, total);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+}  // namespace dt

@@ -1,0 +1,70 @@
+// Shared epilogue of the implicit-GEMM convolution kernels (fp32-MFMA and split-bf16 variants).
+// Accumulator layout (both MFMA families, 32x32 tiles): register r of lane l holds
+// D[row (r&3) + 8*(r>>2) + 4*(l>>5)][col l&31]; a register is therefore a 128-B run of consecutive
+// channels for two pixel rows -> coalesced NHWC stores.
+#pragma once
+#include "dt_internal.h"
+
+namespace dt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain dwordx4 loads, always promoted to VGPRs
+
+template <int MI, int NI>
+__device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
+                                     int half, int l31) {
+  // ---- split-K: park the raw partial sums; splitk_epilogue_kernel finishes the layer
+  if (p.splits > 1) {
+    float *slab = p.slab + (size_t)blockIdx.z * p.M * p.cout_p;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+      if (n >= p.cout_p) continue;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < p.M) slab[(size_t)m * p.cout_p + n] = acc[mi][ni][r];
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue: folded BN, ReLU, time bias, residual; one 128-B channel run per (register, half)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    if (n >= p.cout_p) continue;
+    const float sc = p.scale[n], sh = p.shift[n];
+    float4 w3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.x3) w3 = *reinterpret_cast<const float4 *>(p.w3 + 4 * n);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m >= p.M) continue;
+        float v = acc[mi][ni][r] * sc + sh;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.tb) v += p.tb[(size_t)(m / p.m_per_tb) * p.tb_stride + n];
+        const size_t o = (size_t)m * p.cout_p + n;
+        if (p.add) v += p.add[o];
+        if (p.x3) {
+          const float *xr = p.x3 + (size_t)m * p.x3_stride;
+          float rs = w3.w;
+          rs = fmaf(xr[0], w3.x, rs);
+          if (p.x3_c > 1) rs = fmaf(xr[p.x3_step], w3.y, rs);
+          if (p.x3_c > 2) rs = fmaf(xr[2 * p.x3_step], w3.z, rs);
+          v += rs;
+        }
+        p.out[o] = v;
+      }
+    }
+  }
+}
+
+}  // namespace dt

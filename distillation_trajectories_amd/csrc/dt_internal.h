@@ -23,6 +23,7 @@ namespace dt {
 // Off by default; when on, every instrumented launch is bracketed by two event records.
 enum KernelClass {
   KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
+  KC_CONVB_128x128, KC_CONVB_128x64, KC_CONVB_64x128, KC_CONVB_64x64,
   KC_SPLITK_EPILOGUE, KC_IM2COL, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
   KC_WASSERSTEIN, KC_RESAMPLE,
   KC_COUNT
@@ -64,6 +65,7 @@ struct ConvParams {
   int splits;
   float *slab;
   int bm, bn;          // tile override (0 = pick by heuristic); bn = 128 needs n_p % 128 == 0
+  int prec;            // 0: exact fp32 MFMA (w = fp32 pack), 1: split-bf16 (w = bf16x3 pack); both fp32-accurate
   // enc1's 1x1 skip of the C<=4 channel image, recomputed in the epilogue instead of being
   // materialised: add = sum_c x3[m*x3_stride + c*x3_step] * w3[n*4+c] + w3[n*4+3]
   const float *x3;
@@ -72,7 +74,10 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams &p, hipStream_t s);
-struct ConvChoice { int bm, bn, splits; };
+int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s);
+int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int n_p,
+                            int split_c, int split_cp, hipStream_t s);
+struct ConvChoice { int bm, bn, splits, prec; };
 ConvChoice heuristic_choice(int M, int n_p, int taps);
 constexpr int kSplitMaxRows = 32768;   // split-K candidates only below this many GEMM rows (bounds the slab)
 

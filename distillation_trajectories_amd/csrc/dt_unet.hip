@@ -44,7 +44,8 @@ struct Profiler {
 } g_prof;
 const char *kClassName[KC_COUNT] = {
     "conv_gemm_kernel<128,128>", "conv_gemm_kernel<128,64>", "conv_gemm_kernel<64,128>", "conv_gemm_kernel<64,64>",
-    "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
+    "conv_gemm_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
@@ -67,7 +68,8 @@ struct BlockW {
   int cin_p, cout_p, n_p; // padded
   int split_c, split_cp;  // concat split of the input channels (== cin, cin_p when no concat)
   bool has_res;
-  float *w1, *w2, *wr;    // packed conv weights
+  float *w1, *w2, *wr;    // packed conv weights (fp32 tiles)
+  float *w1b, *w2b, *wrb; // the same weights split into three bf16 planes (dt_conv_bf16.hip)
   float *s1, *h1, *s2, *h2, *sr, *hr;  // scale/shift per conv
   float *w3;              // enc1 only: skip weights for the in-epilogue 1x1 (n_p x 4)
   int tb_off;             // channel offset of this block in a time-bias row
@@ -82,6 +84,7 @@ struct TunedShape {
 
 struct dt_unet {
   std::vector<TunedShape> tuned;
+  int precision;          // DT_PREC_*: which convolution arithmetic the heuristic / autotuner may use
   dt_unet_desc desc;
   BlockW blk[kBlocks];
   int cp[4];              // padded dims
@@ -186,8 +189,10 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     }
   }
   ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
+  if (!choice) c.prec = u->precision == DT_PREC_FP32 ? 0 : 1;
   if (taps != 9 || p.M > kSplitMaxRows) c.splits = 1;
-  p.bm = c.bm; p.bn = c.bn; p.splits = c.splits;
+  p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
+  if (c.prec == 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
   return true;
 }
 
@@ -261,6 +266,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   dt_unet *u = new (std::nothrow) dt_unet();
   if (!u) return (int)hipErrorOutOfMemory;
   u->desc = *desc;
+  u->precision = DT_PREC_AUTO;
   const int C = desc->channels, D = desc->temb_dim;
   const int *d = desc->dims;
   for (int i = 0; i < 4; ++i) u->cp[i] = round_up(d[i], kChanPad);
@@ -271,6 +277,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   const int up_c[kBlocks] = {0, 0, 0, 0, 0, d[3], d[2], d[1]};   // channels coming from the upsampled branch
   Bump bump;
   size_t o_w1[kBlocks], o_w2[kBlocks], o_wr[kBlocks], o_ss[kBlocks];
+  size_t o_w1b[kBlocks], o_w2b[kBlocks], o_wrb[kBlocks];   // bf16x3 packs: 6 bytes per weight = 1.5 floats
   int tb = 0;
   for (int j = 0; j < kBlocks; ++j) {
     BlockW &k = u->blk[j];
@@ -293,6 +300,9 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
     o_w2[j] = bump.take((size_t)9 * k.cout_p * k.n_p);
     o_wr[j] = k.has_res ? bump.take(j == 0 ? (size_t)4 * k.n_p : (size_t)k.cin_p * k.n_p) : 0;
     o_ss[j] = bump.take((size_t)6 * k.n_p);
+    o_w1b[j] = bump.take((size_t)(j == 0 ? 1 : 9) * k.cin_p * k.n_p * 3 / 2);
+    o_w2b[j] = bump.take((size_t)9 * k.cout_p * k.n_p * 3 / 2);
+    o_wrb[j] = (k.has_res && j > 0) ? bump.take((size_t)k.cin_p * k.n_p * 3 / 2) : 0;
     k.tb_off = tb;
     tb += k.cout_p;
   }
@@ -319,6 +329,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
     k.w1 = S + o_w1[j]; k.w2 = S + o_w2[j];
     k.wr = (k.has_res && j > 0) ? S + o_wr[j] : nullptr;
     k.w3 = j == 0 ? S + o_wr[j] : nullptr;
+    k.w1b = S + o_w1b[j]; k.w2b = S + o_w2b[j]; k.wrb = (k.has_res && j > 0) ? S + o_wrb[j] : nullptr;
     float *ss = S + o_ss[j];
     k.s1 = ss; k.h1 = ss + k.n_p; k.s2 = ss + 2 * k.n_p; k.h2 = ss + 3 * k.n_p; k.sr = ss + 4 * k.n_p; k.hr = ss + 5 * k.n_p;
     if (j == 0)   // OIHW [cout][C][3][3] read as a [cout][9C] matrix: a 1x1 conv over the im2col patches
@@ -328,6 +339,11 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
     if (!st) st = launch_pack_conv(t[DT_BT_CONV2_W], k.w2, k.cout, k.cout, 3, k.cout_p, k.n_p, k.cout, k.cout_p, s);
     if (!st && k.has_res && j > 0)
       st = launch_pack_conv(t[DT_BT_RES_W], k.wr, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
+    if (!st) st = j == 0 ? launch_pack_conv_bf16x3(t[DT_BT_CONV1_W], k.w1b, k.cout, 9 * C, 1, k.cin_p, k.n_p, 9 * C, k.cin_p, s)
+                         : launch_pack_conv_bf16x3(t[DT_BT_CONV1_W], k.w1b, k.cout, k.cin, 3, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
+    if (!st) st = launch_pack_conv_bf16x3(t[DT_BT_CONV2_W], k.w2b, k.cout, k.cout, 3, k.cout_p, k.n_p, k.cout, k.cout_p, s);
+    if (!st && k.has_res && j > 0)
+      st = launch_pack_conv_bf16x3(t[DT_BT_RES_W], k.wrb, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
     if (!st && j == 0) st = launch_pack_res3(t[DT_BT_RES_W], t[DT_BT_RES_B], k.w3, k.cout, C, k.n_p, s);
     if (!st) st = launch_fold_bn(t[DT_BT_CONV1_B], t[DT_BT_BN1_G], t[DT_BT_BN1_B], t[DT_BT_BN1_MEAN], t[DT_BT_BN1_VAR],
                                  k.s1, k.h1, k.cout, k.n_p, s);
@@ -400,14 +416,18 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       ConvParams p;
       if (!conv_slot(h, j, slot, in, ws, pl, batch_total, tb, batch_total, nullptr, p)) continue;
       const bool can_split = p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && !p.x3 && p.M <= kSplitMaxRows;
-      ConvChoice best{p.bm, p.bn, p.splits};
+      ConvChoice best{p.bm, p.bn, p.splits, p.prec};
       float best_ms = 1e30f;
+      const BlockW &kw = h->blk[j];
+      for (int prec = 0; prec <= 1; ++prec) {
+        if ((h->precision == DT_PREC_FP32 && prec == 1) || (h->precision == DT_PREC_SPLIT_BF16 && prec == 0)) continue;
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
           for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= 3) {
             ConvParams q = p;
-            q.bm = bm; q.bn = bn; q.splits = sp;
+            q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
+            q.w = prec ? (slot == 0 ? kw.wrb : (slot == 1 ? kw.w1b : kw.w2b)) : (slot == 0 ? kw.wr : (slot == 1 ? kw.w1 : kw.w2));
             float ms_min = 1e30f;
             for (int rep = 0; rep < 3 && st == DT_OK; ++rep) {
               (void)hipEventRecord(e0, s);
@@ -418,9 +438,10 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
               (void)hipEventElapsedTime(&ms, e0, e1);
               if (rep > 0 && ms < ms_min) ms_min = ms;   // first repetition warms caches / code
             }
-            if (ms_min < best_ms) { best_ms = ms_min; best = ConvChoice{bm, bn, sp}; }
+            if (ms_min < best_ms) { best_ms = ms_min; best = ConvChoice{bm, bn, sp, prec}; }
           }
         }
+      }
       t.c[j][slot] = best;
     }
   }
@@ -433,21 +454,29 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
   return DT_OK;
 }
 
+int dt_unet_set_precision(dt_unet *h, int precision) {
+  if (!h) return DT_E_NULL;
+  if (precision < DT_PREC_FP32 || precision > DT_PREC_AUTO) return DT_E_ARG;
+  if (precision != h->precision) h->tuned.clear();
+  h->precision = precision;
+  return DT_OK;
+}
+
 /* test / report hook: the (bm, bn, splits) in use for block j, slot (0 skip, 1 conv1, 2 conv2) at a shape */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
-                        int *splits, int *tuned) {
-  if (!h || !bm || !bn || !splits || !tuned) return DT_E_NULL;
+                        int *splits, int *prec, int *tuned) {
+  if (!h || !bm || !bn || !splits || !prec || !tuned) return DT_E_NULL;
   if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H % 16 || W % 16 || batch_total < 1) return DT_E_ARG;
   const Plan pl = make_plan(h, batch_total, H, W);
   const TunedShape *t = find_tuned(h, batch_total, H, W);
   ConvParams p;
   float dummy = 0.f;
   if (!conv_slot(h, block, slot, &dummy, &dummy, pl, batch_total, &dummy, 1, t ? &t->c[block][slot] : nullptr, p)) {
-    *bm = *bn = *splits = 0; *tuned = 0;
+    *bm = *bn = *splits = *prec = 0; *tuned = 0;
     return DT_OK;
   }
   if (!p.bm || !p.bn) { const ConvChoice c = heuristic_choice(p.M, p.n_p, 1); p.bm = c.bm; p.bn = c.bn; }
-  *bm = p.bm; *bn = p.bn; *splits = p.splits; *tuned = t != nullptr;
+  *bm = p.bm; *bn = p.bn; *splits = p.splits; *prec = p.prec; *tuned = t != nullptr;
   return DT_OK;
 }
 

@@ -66,6 +66,8 @@ class UNetHandle:
             torch.cuda.current_stream().synchronize()   # sd / freqs may be freed after this
         self.h = h
         self.tb_stride = self.lib.dt_unet_time_bias_stride(self.h)
+        mode = os.environ.get("DT_PRECISION", "auto")
+        check(self.lib.dt_unet_set_precision(self.h, {"fp32": 0, "split-bf16": 1, "auto": 2}[mode]), "dt_unet_set_precision")
         self._ws = {}
         self._tuned = set()
 
@@ -104,6 +106,11 @@ class UNetHandle:
             ws = self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
         return ws
 
+    def set_precision(self, mode):
+        """PREC_FP32 (exact fp32 MFMA), PREC_SPLIT_BF16 (3-plane bf16 split, 6 products) or PREC_AUTO."""
+        check(self.lib.dt_unet_set_precision(self.h, int(mode)), "dt_unet_set_precision")
+        self._tuned.clear()
+
     def autotune(self, batch_total, H, W):
         """Measure tile / tap-split candidates for this forward shape once and keep the fastest (dt_unet_autotune)."""
         key = (batch_total, H, W)
@@ -120,11 +127,12 @@ class UNetHandle:
         out = []
         for j in range(8):
             for slot in range(3):
-                bm, bn, sp, tu = c_int(), c_int(), c_int(), c_int()
+                bm, bn, sp, pr, tu = c_int(), c_int(), c_int(), c_int(), c_int()
                 check(self.lib.dt_unet_conv_choice(self.h, batch_total, H, W, j, slot, ctypes.byref(bm), ctypes.byref(bn),
-                                                   ctypes.byref(sp), ctypes.byref(tu)), "dt_unet_conv_choice")
+                                                   ctypes.byref(sp), ctypes.byref(pr), ctypes.byref(tu)), "dt_unet_conv_choice")
                 if bm.value:
-                    out.append((BLOCK_NAMES[j], ("skip", "conv1", "conv2")[slot], bm.value, bn.value, sp.value, bool(tu.value)))
+                    out.append((BLOCK_NAMES[j], ("skip", "conv1", "conv2")[slot], bm.value, bn.value, sp.value,
+                                ("fp32", "split-bf16")[pr.value], bool(tu.value)))
         return out
 
     def time_bias(self, t_values, cond_modes):

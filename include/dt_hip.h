@@ -111,9 +111,17 @@ int dt_unet_forward(const dt_unet *h, const float *x_dev, int B, int n_pass, int
  * Results are identical up to fp32 summation order (the split changes the grouping of the tap sum). */
 int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
-/* report hook: tile (bm x bn) and tap split in use for block (0..7), slot (0 skip, 1 conv1, 2 conv2) */
+/* report hook: tile (bm x bn), tap split and arithmetic (0 fp32 MFMA, 1 split-bf16) in use for
+ * block (0..7), slot (0 skip, 1 conv1, 2 conv2) */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
-                        int *splits, int *tuned);
+                        int *splits, int *prec, int *tuned);
+
+/* Convolution arithmetic.  Both variants are fp32-accurate: DT_PREC_FP32 uses the exact fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32); DT_PREC_SPLIT_BF16 splits every fp32 operand exactly into three bf16
+ * planes and sums the six significant plane products on the bf16 matrix cores (fp32 accumulate; the
+ * dropped cross terms are < 2^-25 relative).  DT_PREC_AUTO (default) lets the autotuner pick per layer. */
+enum { DT_PREC_FP32 = 0, DT_PREC_SPLIT_BF16 = 1, DT_PREC_AUTO = 2 };
+int dt_unet_set_precision(dt_unet *h, int precision);
 
 /* test hook: float offset / padded channel count of a block output inside the workspace
  * (which: 0..7 block outputs in DT order), valid after dt_unet_forward with the same shape */
