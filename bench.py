@@ -29,7 +29,11 @@ if ROOT not in sys.path:
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+# /opt/skills/guides/MI355X_MICROARCH.md: dense matrix peaks.  The split-bf16 kernels evaluate every fp32
+# product as 6 bf16 plane products, so their fp32-equivalent ceiling is the dense bf16 peak / 6.
+PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PLANE_PRODUCTS = 6
 T, BATCH, H, C = 50, 256, 16, 3
 TEACHER_SF, STUDENT_SF = 1.0, 0.5
 GUIDANCE = 1.0
@@ -147,6 +151,17 @@ def cpu_baseline(batch=256, steps=8, pairs=8):
                       f"sampler {t_sample:.2f}s, metrics {t_metric_pair * 1e3:.1f} ms/pair"}
 
 
+def traffic_from_profiles(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 note), or None if not recorded."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel_name)
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,7 +222,9 @@ def main():
         "metric": "trajectory-timesteps/sec (B×T U-Net fwd) at 16×16 T=50",
         "value": round(value, 1), "unit": "trajectory-timesteps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (fp32-accurate; convolutions: exact 3-plane bf16 operand split on bf16 MFMA with fp32 accumulate, or "
+                 "native fp32 MFMA, chosen per layer)", "data": "synthetic",
         "config": {"workload": "configs[1]: teacher sf=1.0 vs student sf=0.5, 16x16x3, T=50, batch 256/GPU, "
                                "p_sample_loop CFG (2 U-Net passes/step, w=1.0) + trajectory metrics of the 256 pairs",
                    "batch_per_gpu": args.batch, "timesteps": T, "image": [C, H, H], "guidance_scale": GUIDANCE,
@@ -223,14 +240,19 @@ def main():
         conv = {n: k for n, k in kernels.items() if n.startswith("conv_gemm")}
         conv_ms, conv_fl = sum(k["ms"] for k in conv.values()), sum(k["flops"] for k in conv.values())
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        split = "bf16x6" in dom_name
+        peak = PEAK_BF16_MFMA_TFLOPS / PLANE_PRODUCTS if split else PEAK_FP32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
-                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                           "traffic": None, "launches": dom["launches"],
+                           "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                           "peak_basis": ("dense bf16 MFMA 2500 TF/s / 6 plane products per fp32-accurate product; "
+                                          f"issued bf16 MFMA rate {achieved * PLANE_PRODUCTS:.0f} TF/s; native fp32 MFMA "
+                                          f"peak is {PEAK_FP32_MFMA_TFLOPS} TF/s") if split else "dense fp32 MFMA",
+                           "traffic": traffic_from_profiles(dom_name), "launches": dom["launches"],
                            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                            "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                            "share_of_kernel_time": round(dom["ms"] / total_ms, 3),
                            "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
-                           "all_conv_frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "all_conv_vs_native_fp32_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                            "timed_with": f"hipEventRecord pairs around every launch, second pass of the same {args.steps} "
                                          f"steps ({profiled_elapsed / args.steps * 1e3:.1f} ms/step with events vs "
                                          f"{elapsed / args.steps * 1e3:.1f} ms/step in the timed region)"}

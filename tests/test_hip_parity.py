@@ -367,3 +367,39 @@ def test_wasserstein_subsampled_tables():
             idx = np.random.choice(E, 1000, replace=False)
             want = wasserstein_distance(X[i, b].numpy()[idx], Y[i, b].numpy()[idx])
             assert abs(got[b, i] - want) <= 1e-12 + 1e-9 * want
+
+
+# ------------------------------------------------------------------ both convolution arithmetics are fp32-accurate
+def test_conv_arithmetic_accuracy_vs_float64(models):
+    """Exact-fp32 MFMA and split-bf16 (3 planes, 6 products) against a float64 evaluation of the same
+    U-Net: both must sit at fp32 rounding level, and the split path must not be worse than 2x the native one."""
+    import copy
+    import torch.nn.functional as F
+    sd64 = {k: v.double() for k, v in models(0.5).state_dict().items() if v.dtype.is_floating_point}
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(16, 3, 16, 16, generator=g)
+    t = torch.full((16,), 23, dtype=torch.long)
+    up = lambda a: F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)   # noqa: E731
+    with torch.no_grad():
+        sd32 = models(0.5).state_dict()
+        temb = unet_ref.time_embedding(sd32, t, torch.ones(16, 1)).double()   # embedding tower: fp32 oracle (tiny)
+        x1 = unet_ref.block_forward(sd64, "enc1", x.double(), temb)
+        x2 = unet_ref.block_forward(sd64, "enc2", F.max_pool2d(x1, 2), temb)
+        x3 = unet_ref.block_forward(sd64, "enc3", F.max_pool2d(x2, 2), temb)
+        x4 = unet_ref.block_forward(sd64, "enc4", F.max_pool2d(x3, 2), temb)
+        xb = unet_ref.block_forward(sd64, "bottleneck", F.max_pool2d(x4, 2), temb)
+        d3 = unet_ref.block_forward(sd64, "dec3", torch.cat([up(xb), x4], 1), temb)
+        d2 = unet_ref.block_forward(sd64, "dec2", torch.cat([up(d3), x3], 1), temb)
+        d1 = unet_ref.block_forward(sd64, "dec1", torch.cat([up(d2), x2], 1), temb)
+        want = F.conv2d(up(d1), sd64["final.weight"], sd64["final.bias"])
+    m = copy.deepcopy(models(0.5)).to(DEV)
+    h = engine.UNetHandle.for_module(m)
+    errs = {}
+    for name, mode in (("fp32", _hip.PREC_FP32), ("split-bf16", _hip.PREC_SPLIT_BF16)):
+        h.set_precision(mode)
+        got = m(x.to(DEV), t.to(DEV), torch.ones(16, 1, device=DEV)).double().cpu()
+        errs[name] = ((got - want).norm() / want.norm()).item()
+    h.set_precision(_hip.PREC_AUTO)
+    print("relative L2 error vs float64:", errs)
+    assert errs["fp32"] < 2e-6 and errs["split-bf16"] < 2e-6, errs
+    assert errs["split-bf16"] <= 2.0 * errs["fp32"] + 1e-7, errs
