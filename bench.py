@@ -20,6 +20,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -47,13 +48,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (default: the configs[1] batch)")
+    ap.add_argument("--serial", action="store_true", help="run the teacher and student loops back to back on one stream")
     return ap.parse_args()
 
 
 class Workload:
     """Device-resident state of one rank's share of the benchmark."""
 
-    def __init__(self, device, rank, batch):
+    def __init__(self, device, rank, batch, concurrent=True):
         from distillation_trajectories_amd import engine
         from distillation_trajectories_amd._hip import COND_NONE, COND_ONE
         from distillation_trajectories_amd.config import Config
@@ -80,19 +82,46 @@ class Workload:
             k += int(flag)
         self.tb = [h.time_bias([i for i in idx for _ in (0, 1)], [COND_NONE, COND_ONE] * T) for h in self.handles]
         self.traj = [torch.empty(T + 1, batch, self.E, device=device) for _ in self.handles]
-        for h in self.handles:
-            h.workspace(2 * batch, H, H)
+        for h, tb in zip(self.handles, self.tb):
+            # tile / split / arithmetic autotuning happens here, one model at a time on an idle GPU
+            h.forward(self.x_T.reshape(batch, C, H, H), tb[:2].contiguous(), 2, batch, tune=True)
+        torch.cuda.synchronize()
         self.choices = None
+        self.concurrent = concurrent
+        self.streams = [torch.cuda.Stream(device=device) for _ in self.handles]
 
     def step(self, world, counts):
         """One pass of the hot path: both samplers, the metric reductions, the metric all-gather."""
         from distillation_trajectories_amd._hip import RULE_PSAMPLE
         from distillation_trajectories_amd.grid import all_gather_rows
         eng = self.engine
-        for h, tb, traj in zip(self.handles, self.tb, self.traj):
+
+        def run(i):
+            h, tb, traj = self.handles[i], self.tb[i], self.traj[i]
             traj[0].copy_(self.x_T)
             h.sample(RULE_PSAMPLE, traj, H, H, tb, 2, self.coef, self.has_noise, z=self.z, z_shift=self.z_shift,
                      w_scalar=GUIDANCE)
+        if self.concurrent:
+            # teacher and student loops are independent: one HIP stream + one host thread each (the C call
+            # releases the GIL), so the small spatial levels of one model overlap the other's work
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+
+            def worker(i):
+                with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
+                    self.streams[i].wait_event(ready)
+                    run(i)
+            threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(self.handles))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for st in self.streams:
+                main.wait_stream(st)
+        else:
+            for i in range(len(self.handles)):
+                run(i)
         sums = eng.device_metric_sums(self.traj[0], self.traj[1])          # [B, T+1, 4] float64
         w1 = eng.device_wasserstein(self.traj[0], self.traj[1])            # [B, T+1]   float64
         local = torch.cat([sums.reshape(self.B, -1), w1], dim=1)
@@ -180,7 +209,7 @@ def main():
 
     from distillation_trajectories_amd import _hip
     _hip.load()
-    wl = Workload(device, rank, args.batch)
+    wl = Workload(device, rank, args.batch, concurrent=not args.serial)
     counts = [args.batch] * world
 
     def barrier():
@@ -206,6 +235,7 @@ def main():
     # so this pass is kept out of `value` and its own wall time is reported beside it)
     kernels, profiled_elapsed = {}, None
     if not args.no_profile and rank == 0:
+        wl.concurrent = False      # one stream: per-kernel durations free of cross-stream contention
         _hip.profile_begin()
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -254,8 +284,9 @@ def main():
                            "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                            "all_conv_vs_native_fp32_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                            "timed_with": f"hipEventRecord pairs around every launch, second pass of the same {args.steps} "
-                                         f"steps ({profiled_elapsed / args.steps * 1e3:.1f} ms/step with events vs "
-                                         f"{elapsed / args.steps * 1e3:.1f} ms/step in the timed region)"}
+                                         f"steps on ONE stream ({profiled_elapsed / args.steps * 1e3:.1f} ms/step with events vs "
+                                         f"{elapsed / args.steps * 1e3:.1f} ms/step in the timed region, where the teacher and "
+                                         "student loops run on two streams)"}
         out["tile_choices"] = wl.choices
         out["kernels"] = {n: {"launches": k["launches"], "ms": round(k["ms"], 3),
                               "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["flops"] else None,

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
   const int CC = p.cin_p >> 4;                  // 16-channel chunks per tap
 
   // ---- per-thread staging coordinates (fixed for the whole K walk)
-  int a_off[A_PER], a_y[A_PER], a_x[A_PER];
+  int a_off[A_PER], a_off2[A_PER], a_y[A_PER], a_x[A_PER];
   bool a_ok[A_PER];
   int a_lds[A_PER];
 #pragma unroll
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
     a_y[j] = rem / p.W;
     a_x[j] = rem - a_y[j] * p.W;
     a_off[j] = mm * p.cin_p + lslot * 4;       // M*cin_p < 2^31 is checked by the host
+    a_off2[j] = mm * p.cin2_p + lslot * 4;     // fused skip walk (same pixel, other tensor)
     a_lds[j] = q * 4;
   }
   const float *wbase = p.w + (size_t)n0 * 16 + tid * 4;
@@ -72,12 +73,21 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
   // into registers, runs the MFMAs of chunk it from LDS stage it&1, then parks the registers in the
   // other stage.  it == -1 is the prologue (loads chunk 0, no compute).
   const int taps_per = (p.tap_hi - p.tap_lo) / p.splits;
-  const int n_iter = taps_per * CC;
+  const int n_main = taps_per * CC;
+  const int n_iter = n_main + (p.in2 ? (p.cin2_p >> 4) : 0);   // main walk, then the fused 1x1 skip walk
   int tap = p.tap_lo + blockIdx.z * taps_per, cc = 0;
   for (int it = -1; it < n_iter; ++it) {
     const bool more = it + 1 < n_iter;
     f32x4 ra[A_PER], rb[B_PER];
-    if (more) {
+    if (more && it + 1 >= n_main) {
+      const int c2 = it + 1 - n_main;
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j)
+        ra[j] = a_ok[j] ? *reinterpret_cast<const f32x4 *>(p.in2 + a_off2[j] + c2 * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const float *wt = p.w2 + (size_t)n0 * 16 + tid * 4 + (size_t)c2 * p.n_p * 16;
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) rb[j] = *reinterpret_cast<const f32x4 *>(wt + j * 1024);
+    } else if (more) {
       int dy = 0, dx = 0;
       if (p.ksize == 3) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
       const int shift = (dy * p.W + dx) * p.cin_p + cc * 16;
@@ -93,6 +103,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
       if (++cc == CC) { cc = 0; ++tap; }
     }
     if (it >= 0) {
+      if (it == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
       const float *A = lds + (it & 1) * STAGE, *B = A + BM * 16;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -142,7 +153,8 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   if (p.splits < 1 || (p.tap_hi - p.tap_lo) % p.splits || (p.splits > 1 && !p.slab)) return DT_E_ARG;
   // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
-  const double flops = 2.0 * p.M * (double)p.cout_real * p.cin_real * p.ksize * p.ksize;
+  if (p.in2 && (p.splits != 1 || !p.w2 || !p.bias2 || p.cin2_p % 16)) return DT_E_ARG;
+  const double flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));
   if (p.prec == 1) {
     ProfileScope prof(tall_m ? (wide_n ? KC_CONVB_128x128 : KC_CONVB_128x64) : (wide_n ? KC_CONVB_64x128 : KC_CONVB_64x64),
                       flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
@@ -173,6 +185,7 @@ ConvChoice heuristic_choice(int M, int n_p, int taps) {
   c.splits = 1;
   c.prec = 0;
   if (taps == 9 && M <= kSplitMaxRows && blocks < 384) c.splits = blocks * 3 >= 384 ? 3 : 9;
+  c.fuse = c.splits == 1;   // fold a block's 1x1 skip into conv2 whenever conv2 is not tap-split
   return c;
 }
 

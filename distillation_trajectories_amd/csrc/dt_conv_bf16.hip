@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
   const int a_b = a_mm / HW, a_rem = a_mm - a_b * HW;
   const int a_y = a_rem / p.W, a_x = a_rem - a_y * p.W;
   const int a_off = a_mm * p.cin_p + a_hh * 8;
+  const int a_off2 = a_mm * p.cin2_p + a_hh * 8;                    // fused skip walk
   const int a_lds = a_rowi * 16 + ((a_hh ^ ((a_rowi >> 3) & 1)) << 3);   // element offset inside a plane
   // ---- B staging: the three plane tiles are contiguous [BN][16] bf16 runs in the packed weights
   const bool b_thread = tid < BN * 2;
@@ -91,13 +92,26 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
   }
 
   const int taps_per = (p.tap_hi - p.tap_lo) / p.splits;
-  const int n_iter = taps_per * CC;
+  const int n_main = taps_per * CC;
+  const int n_iter = n_main + (p.in2 ? (p.cin2_p >> 4) : 0);       // main walk, then the fused 1x1 skip walk
   int tap = p.tap_lo + blockIdx.z * taps_per, cc = 0;
   for (int it = -1; it < n_iter; ++it) {
     const bool more = it + 1 < n_iter;
     f32x4 ra0 = {0.f, 0.f, 0.f, 0.f}, ra1 = ra0;
     u32x4 rb[3];
-    if (more) {
+    if (more && it + 1 >= n_main) {
+      const int c2 = it + 1 - n_main;
+      if (a_ok) {
+        const float *src = p.in2 + a_off2 + c2 * 16;
+        ra0 = *reinterpret_cast<const f32x4 *>(src);
+        ra1 = *reinterpret_cast<const f32x4 *>(src + 4);
+      }
+      if (b_thread) {
+        const __bf16 *wt = reinterpret_cast<const __bf16 *>(p.w2) + (size_t)n0 * 16 + tid * 8 + (size_t)c2 * 3 * w_plane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rb[pl] = *reinterpret_cast<const u32x4 *>(wt + pl * w_plane);
+      }
+    } else if (more) {
       int dy = 0, dx = 0;
       if (p.ksize == 3) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
       const int yy = a_y + dy, xx = a_x + dx;
@@ -114,6 +128,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
       if (++cc == CC) { cc = 0; ++tap; }
     }
     if (it >= 0) {
+      if (it == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
       const __bf16 *A = lds + (it & 1) * STAGE, *B = A + 3 * PLANE_A;
       bf16x8 fb[NI][3];
 #pragma unroll

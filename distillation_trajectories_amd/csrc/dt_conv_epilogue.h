@@ -48,8 +48,13 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
         if (m >= p.M) continue;
-        float v = acc[mi][ni][r] * sc + sh;
-        if (p.relu) v = fmaxf(v, 0.f);
+        float v;
+        if (p.in2) {
+          v = acc[mi][ni][r] + p.bias2[n];       // BN/ReLU were applied in registers before the skip walk
+        } else {
+          v = acc[mi][ni][r] * sc + sh;
+          if (p.relu) v = fmaxf(v, 0.f);
+        }
         if (p.tb) v += p.tb[(size_t)(m / p.m_per_tb) * p.tb_stride + n];
         const size_t o = (size_t)m * p.cout_p + n;
         if (p.add) v += p.add[o];
@@ -64,6 +69,23 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
         p.out[o] = v;
       }
     }
+  }
+}
+
+// relu(acc*scale+shift) in registers, between the main K walk and the fused skip walk
+template <int MI, int NI>
+__device__ inline void conv_midpoint(const ConvParams &p, f32x16 (&acc)[MI][NI], int n0, int wn, int l31) {
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    const float sc = p.scale[n], sh = p.shift[n];   // arrays are n_p long: always in range
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[mi][ni][r] * sc + sh;
+        acc[mi][ni][r] = p.relu ? fmaxf(v, 0.f) : v;
+      }
   }
 }
 

@@ -71,13 +71,21 @@ struct ConvParams {
   const float *x3;
   const float *w3;
   int x3_stride, x3_step, x3_c;
+  // fused 1x1 skip (splits == 1 only): after the last chunk of the main K walk the accumulators become
+  // relu(acc*scale+shift) IN REGISTERS, then the walk continues over in2[M][cin2_p] x w2 (the block's
+  // residual_conv) on the same accumulators; the epilogue only adds bias2.  Saves the skip launch and the
+  // round trip of its [M][cout_p] output through HBM.
+  const float *in2;
+  const float *w2;
+  const float *bias2;
+  int cin2_p, cin2_real;
 };
 
 int launch_conv(const ConvParams &p, hipStream_t s);
 int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s);
 int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int n_p,
                             int split_c, int split_cp, hipStream_t s);
-struct ConvChoice { int bm, bn, splits, prec; };
+struct ConvChoice { int bm, bn, splits, prec, fuse; };
 ConvChoice heuristic_choice(int M, int n_p, int taps);
 constexpr int kSplitMaxRows = 32768;   // split-K candidates only below this many GEMM rows (bounds the slab)
 

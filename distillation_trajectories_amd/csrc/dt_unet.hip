@@ -7,6 +7,7 @@
 //   up+cat(enc4) -> dec3 @H/8 -> up+cat(enc3) -> dec2 @H/4 -> up+cat(enc2) -> dec1 @H/2 -> up + 1x1 head @H
 // Each residual block is up to three implicit-GEMM launches (1x1 skip, conv1, conv2) whose epilogues
 // carry BN/ReLU/time-bias/residual, so a forward is 8 blocks * (2..3) + 4 pools + 3 upcats + 2 = ~32 launches.
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -29,6 +30,7 @@ using namespace dt;
 namespace {
 struct ProfRecord { hipEvent_t a, b; int cls; double flops, bytes; };
 struct Profiler {
+  std::mutex mu;          // launches may come from several host threads (one per stream)
   bool on = false;
   std::vector<ProfRecord> rec;
   std::vector<hipEvent_t> pool;     // events are recycled between sessions
@@ -52,14 +54,25 @@ const char *kClassName[KC_COUNT] = {
 namespace dt {
 ProfileScope::ProfileScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
   if (!g_prof.on) return;
-  hipEvent_t a = g_prof.get(), b = g_prof.get();
-  if (!a || !b) return;
-  g_prof.rec.push_back(ProfRecord{a, b, cls, flops, bytes});
-  slot = (int)g_prof.rec.size() - 1;
+  hipEvent_t a;
+  {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    a = g_prof.get();
+    hipEvent_t b = g_prof.get();
+    if (!a || !b) return;
+    g_prof.rec.push_back(ProfRecord{a, b, cls, flops, bytes});
+    slot = (int)g_prof.rec.size() - 1;
+  }
   (void)hipEventRecord(a, s);
 }
 ProfileScope::~ProfileScope() {
-  if (slot >= 0) (void)hipEventRecord(g_prof.rec[slot].b, stream);
+  if (slot < 0) return;
+  hipEvent_t b;
+  {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    b = g_prof.rec[slot].b;
+  }
+  (void)hipEventRecord(b, stream);
 }
 }  // namespace dt
 
@@ -193,13 +206,25 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   if (taps != 9 || p.M > kSplitMaxRows) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
   if (c.prec == 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
+  if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0) {
+    // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
+    p.add = nullptr;
+    p.in2 = in; p.w2 = c.prec == 1 ? k.wrb : k.wr; p.bias2 = k.hr; p.cin2_p = k.cin_p; p.cin2_real = k.cin;
+  }
   return true;
 }
 
 int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
               const TunedShape *tuned, hipStream_t s) {
   ConvParams p;
+  bool fused_skip = false;
+  if (u->blk[j].has_res && j > 0) {   // is conv2 going to fold the skip in?
+    ConvParams c2;
+    conv_slot(u, j, 2, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][2] : nullptr, c2);
+    fused_skip = c2.in2 != nullptr;
+  }
   for (int slot = 0; slot < 3; ++slot) {
+    if (slot == 0 && fused_skip) continue;
     if (!conv_slot(u, j, slot, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][slot] : nullptr, p)) continue;
     const int st = launch_conv(p, s);
     if (st) return st;
@@ -412,22 +437,33 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
   int st = DT_OK;
   for (int j = 0; j < kBlocks && st == DT_OK; ++j) {
     const float *in = j == 0 ? ws + pl.a0 : (j <= 4 ? ws + pl.pool[j - 1] : ws + pl.cat[j - 5]);
+    float skip_ms = 0.f;
     for (int slot = 0; slot < 3 && st == DT_OK; ++slot) {
       ConvParams p;
       if (!conv_slot(h, j, slot, in, ws, pl, batch_total, tb, batch_total, nullptr, p)) continue;
+      {   // candidates start from the UNFUSED launch (the heuristic may have folded the skip in)
+        const ConvChoice unfused{p.bm, p.bn, p.splits, p.prec, 0};
+        conv_slot(h, j, slot, in, ws, pl, batch_total, tb, batch_total, &unfused, p);
+      }
       const bool can_split = p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && !p.x3 && p.M <= kSplitMaxRows;
-      ConvChoice best{p.bm, p.bn, p.splits, p.prec};
+      ConvChoice best{p.bm, p.bn, p.splits, p.prec, 0};
       float best_ms = 1e30f;
+      const bool can_fuse = slot == 2 && j > 0 && h->blk[j].has_res;
       const BlockW &kw = h->blk[j];
       for (int prec = 0; prec <= 1; ++prec) {
         if ((h->precision == DT_PREC_FP32 && prec == 1) || (h->precision == DT_PREC_SPLIT_BF16 && prec == 0)) continue;
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
-          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= 3) {
+          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= 3)
+          for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
             q.w = prec ? (slot == 0 ? kw.wrb : (slot == 1 ? kw.w1b : kw.w2b)) : (slot == 0 ? kw.wr : (slot == 1 ? kw.w1 : kw.w2));
+            if (fuse) {
+              q.add = nullptr; q.in2 = in; q.w2 = prec ? kw.wrb : kw.wr; q.bias2 = kw.hr; q.cin2_p = kw.cin_p;
+              q.cin2_real = kw.cin;
+            }
             float ms_min = 1e30f;
             for (int rep = 0; rep < 3 && st == DT_OK; ++rep) {
               (void)hipEventRecord(e0, s);
@@ -438,11 +474,14 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
               (void)hipEventElapsedTime(&ms, e0, e1);
               if (rep > 0 && ms < ms_min) ms_min = ms;   // first repetition warms caches / code
             }
-            if (ms_min < best_ms) { best_ms = ms_min; best = ConvChoice{bm, bn, sp, prec}; }
+            // a fused conv2 also saves the separate skip launch measured for slot 0
+            const float cost = ms_min + (fuse ? 0.f : (can_fuse ? skip_ms : 0.f));
+            if (cost < best_ms) { best_ms = cost; best = ConvChoice{bm, bn, sp, prec, fuse}; }
           }
         }
       }
       t.c[j][slot] = best;
+      if (slot == 0) skip_ms = best_ms;
     }
   }
   (void)hipEventDestroy(e0);
@@ -476,7 +515,12 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
     return DT_OK;
   }
   if (!p.bm || !p.bn) { const ConvChoice c = heuristic_choice(p.M, p.n_p, 1); p.bm = c.bm; p.bn = c.bn; }
-  *bm = p.bm; *bn = p.bn; *splits = p.splits; *prec = p.prec; *tuned = t != nullptr;
+  *bm = p.bm; *bn = p.bn; *splits = p.splits; *prec = p.prec + (p.in2 ? 2 : 0); *tuned = t != nullptr;
+  if (slot == 0) {   // folded into conv2?
+    ConvParams c2;
+    conv_slot(h, block, 2, &dummy, &dummy, pl, batch_total, &dummy, 1, t ? &t->c[block][2] : nullptr, c2);
+    if (c2.in2) *bm = *bn = *splits = 0;
+  }
   return DT_OK;
 }
 

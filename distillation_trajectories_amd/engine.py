@@ -8,6 +8,7 @@ device -- the product has no CPU path (the CPU restatement lives in oracle/ and 
 import ctypes
 import math
 import os
+import sys
 from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 import numpy as np
@@ -73,7 +74,7 @@ class UNetHandle:
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
-        if h:
+        if h and not sys.is_finalizing():        # at interpreter exit the HIP runtime may already be gone
             try:
                 self.lib.dt_unet_destroy(h)
             except Exception:
@@ -132,7 +133,7 @@ class UNetHandle:
                                                    ctypes.byref(sp), ctypes.byref(pr), ctypes.byref(tu)), "dt_unet_conv_choice")
                 if bm.value:
                     out.append((BLOCK_NAMES[j], ("skip", "conv1", "conv2")[slot], bm.value, bn.value, sp.value,
-                                ("fp32", "split-bf16")[pr.value], bool(tu.value)))
+                                ("fp32", "split-bf16", "fp32+skip", "split-bf16+skip")[pr.value], bool(tu.value)))
         return out
 
     def time_bias(self, t_values, cond_modes):

@@ -111,8 +111,9 @@ int dt_unet_forward(const dt_unet *h, const float *x_dev, int B, int n_pass, int
  * Results are identical up to fp32 summation order (the split changes the grouping of the tap sum). */
 int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
-/* report hook: tile (bm x bn), tap split and arithmetic (0 fp32 MFMA, 1 split-bf16) in use for
- * block (0..7), slot (0 skip, 1 conv1, 2 conv2) */
+/* report hook: tile (bm x bn), tap split and arithmetic (0 fp32 MFMA, 1 split-bf16; +2 when the block's
+ * 1x1 skip is folded into this conv2 launch) in use for block (0..7), slot (0 skip, 1 conv1, 2 conv2);
+ * bm = 0 means the slot has no launch of its own */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
                         int *splits, int *prec, int *tuned);
 

@@ -117,11 +117,18 @@ def test_unet_forward_large_batch_properties(gpu_models):
     solo_c = h.forward(x, tb[1:2].contiguous(), 1, 256)
     assert_close(solo_u.cpu().numpy(), both[:256].cpu().numpy(), rtol=1e-5, atol=1e-6, what='solo uncond')
     assert_close(solo_c.cpu().numpy(), both[256:].cpu().numpy(), rtol=1e-5, atol=1e-6, what='solo cond')
-    # oracle spot check on 4 rows
+    # oracle spot check on 4 rows, for the autotuned plan and for the untuned heuristic plan in both arithmetics
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():
         want = unet_ref.unet_forward(sd, x[:4].cpu(), torch.full((4,), 17), torch.ones(4, 1))
     assert_close(both[256:260].cpu().numpy(), want.numpy(), what="cond rows")
+    for mode in (_hip.PREC_FP32, _hip.PREC_SPLIT_BF16):
+        h.set_precision(mode)                        # also drops the tuned plan
+        plain = h.forward(x, tb, 2, 256, tune=False)
+        kinds = {c[5] for c in h.conv_choices(512, 16, 16)}
+        assert any(k.endswith("+skip") for k in kinds), kinds     # the fused-skip walk is exercised
+        assert_close(plain[256:260].cpu().numpy(), want.numpy(), what=f"heuristic plan, mode {mode}")
+    h.set_precision(_hip.PREC_AUTO)
 
 
 def test_time_bias_rows(gpu_models):
