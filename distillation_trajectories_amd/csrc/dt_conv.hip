@@ -155,7 +155,12 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
   // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
   if (p.in2 && (p.splits != 1 || !p.w2 || !p.bias2 || p.cin2_p % 16)) return DT_E_ARG;
   const double flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));
-  if (p.prec == 1) {
+  if (p.prec == 2) {
+    ProfileScope prof(tall_m ? (wide_n ? KC_CONVD_128x128 : KC_CONVD_128x64) : (wide_n ? KC_CONVD_64x128 : KC_CONVD_64x64),
+                      flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
+    const int st = launch_conv_bf16x6_dma(p, bm, bn, s);
+    if (st) return st;
+  } else if (p.prec == 1) {
     ProfileScope prof(tall_m ? (wide_n ? KC_CONVB_128x128 : KC_CONVB_128x64) : (wide_n ? KC_CONVB_64x128 : KC_CONVB_64x64),
                       flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
     const int st = launch_conv_bf16x6(p, bm, bn, s);
@@ -215,6 +220,17 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     *reinterpret_cast<float4 *>(p.out + o) = v;
+    if (p.out_pl) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 q1, q2, q3;
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { __bf16 a1, a2, a3; split3(vv[e], a1, a2, a3); q1[e] = a1; q2[e] = a2; q3[e] = a3; }
+      __bf16 *pl = reinterpret_cast<__bf16 *>(p.out_pl) + plane_index(m, n, p.cout_p >> 4);
+      *reinterpret_cast<bf16x4 *>(pl) = q1;
+      *reinterpret_cast<bf16x4 *>(pl + 16) = q2;
+      *reinterpret_cast<bf16x4 *>(pl + 32) = q3;
+    }
   }
 }
 

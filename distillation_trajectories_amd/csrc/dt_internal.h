@@ -24,6 +24,7 @@ namespace dt {
 enum KernelClass {
   KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
   KC_CONVB_128x128, KC_CONVB_128x64, KC_CONVB_64x128, KC_CONVB_64x64,
+  KC_CONVD_128x128, KC_CONVD_128x64, KC_CONVD_64x128, KC_CONVD_64x64,
   KC_SPLITK_EPILOGUE, KC_IM2COL, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
   KC_WASSERSTEIN, KC_RESAMPLE,
   KC_COUNT
@@ -79,10 +80,15 @@ struct ConvParams {
   const float *w2;
   const float *bias2;
   int cin2_p, cin2_real;
+  // bf16 "planes" twins [M][C/16][3][16] of activation tensors (exact 3-way split, see dt_conv_dma.hip):
+  // inputs of the LDS-DMA kernel (prec == 2) and, when out_pl is set, an extra output of the epilogue
+  const void *in_pl, *in2_pl, *zero;
+  void *out_pl;
 };
 
 int launch_conv(const ConvParams &p, hipStream_t s);
 int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s);
+int launch_conv_bf16x6_dma(const ConvParams &p, int bm, int bn, hipStream_t s);
 int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int n_p,
                             int split_c, int split_cp, hipStream_t s);
 struct ConvChoice { int bm, bn, splits, prec, fuse; };
@@ -97,8 +103,9 @@ int launch_pack_linear_rows(const float *w, const float *b, float *wp, float *bp
                             hipStream_t s);
 
 int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, int W, int kp, hipStream_t s);
-int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s);
-int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p, hipStream_t s);
+int launch_maxpool(const float *in, float *out, void *out_pl, int Bt, int H, int W, int cp, hipStream_t s);
+int launch_upcat(const float *lo, const float *skip, float *out, void *out_pl, int Bt, int h, int w, int c1p, int c2p,
+                 hipStream_t s);
 int launch_head(const float *lo, const float *w, const float *bias, float *lowres, float *eps, int Bt, int h, int w_,
                 int cp, int C, int c_real, hipStream_t s);
 int launch_pack_res3(const float *w, const float *b, float *w3, int cout, int C, int n_p, hipStream_t s);

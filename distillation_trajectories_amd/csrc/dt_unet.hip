@@ -47,7 +47,8 @@ struct Profiler {
 const char *kClassName[KC_COUNT] = {
     "conv_gemm_kernel<128,128>", "conv_gemm_kernel<128,64>", "conv_gemm_kernel<64,128>", "conv_gemm_kernel<64,64>",
     "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
-    "conv_gemm_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "conv_gemm_bf16x6_kernel<64,64>", "conv_gemm_bf16x6_dma_kernel<128,128>", "conv_gemm_bf16x6_dma_kernel<128,64>",
+    "conv_gemm_bf16x6_dma_kernel<64,128>", "conv_gemm_bf16x6_dma_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
@@ -98,6 +99,8 @@ struct TunedShape {
 struct dt_unet {
   std::vector<TunedShape> tuned;
   int precision;          // DT_PREC_*: which convolution arithmetic the heuristic / autotuner may use
+  bool planes;            // producers also emit bf16 plane twins, enabling the LDS-DMA conv (prec 2)
+  float *zero_page;       // 256 B of zeros inside the slab (source of out-of-image DMA lanes)
   dt_unet_desc desc;
   BlockW blk[kBlocks];
   int cp[4];              // padded dims
@@ -122,6 +125,7 @@ struct Plan {
   size_t h[kBlocks], r[kBlocks], o[kBlocks];   // conv1 out, skip out, block out
   size_t pool[4], cat[3];
   size_t slab, lowres;                         // split-K partial sums; low-resolution head output
+  size_t h_pl[kBlocks], pool_pl[4], cat_pl[3]; // bf16 plane twins (0 when the handle does not use them)
   size_t total;
   int H[kBlocks], W[kBlocks];                  // spatial size of each block
 };
@@ -141,6 +145,11 @@ Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
     if (j >= 1 && j <= 4) p.pool[j - 1] = b.take(px * u->blk[j].cin_p);
     if (j >= 5) p.cat[j - 5] = b.take(px * u->blk[j].cin_p);
     p.h[j] = b.take(px * u->blk[j].cout_p);
+    if (u->planes) {
+      if (j >= 1 && j <= 4) p.pool_pl[j - 1] = b.take(px * u->blk[j].cin_p * 3 / 2);
+      if (j >= 5) p.cat_pl[j - 5] = b.take(px * u->blk[j].cin_p * 3 / 2);
+      p.h_pl[j] = b.take(px * u->blk[j].cout_p * 3 / 2);
+    }
     p.r[j] = (u->blk[j].has_res && j > 0) ? b.take(px * u->blk[j].cout_p) : 0;
     p.o[j] = b.take(px * u->blk[j].cout_p);
     if (j > 0 && !(h == 1 && w == 1) && px <= (size_t)kSplitMaxRows) {
@@ -164,6 +173,9 @@ const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W) {
 // block has no such launch (identity skips, and enc1 whose skip is recomputed in conv2's epilogue).
 bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, const Plan &pl, int Bt, const float *tb,
                int tb_div, const ConvChoice *choice, ConvParams &p) {
+  // plane twin of the block input (pool / concat output); enc1's input are im2col patches (no twin)
+  const void *in_pl = nullptr;
+  if (u->planes && j >= 1) in_pl = ws + (j <= 4 ? pl.pool_pl[j - 1] : pl.cat_pl[j - 5]);
   const BlockW &k = u->blk[j];
   const int h = pl.H[j], w = pl.W[j];
   const bool dot = h == 1 && w == 1;   // a 1x1 image only ever sees the centre tap of a padded 3x3 kernel
@@ -174,6 +186,8 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   p.tb_stride = u->tb_stride; p.m_per_tb = h * w * tb_div;
   p.slab = ws + pl.slab;
   p.in = in;
+  p.in_pl = in_pl;
+  p.zero = u->zero_page;
   int taps = 1;
   if (slot == 0) {
     if (!k.has_res || j == 0) return false;
@@ -181,6 +195,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1; p.relu = 0;
   } else if (slot == 1) {
     p.w = k.w1; p.scale = k.s1; p.shift = k.h1; p.tb = tb + k.tb_off; p.out = ws + pl.h[j]; p.relu = 1;
+    if (u->planes) p.out_pl = ws + pl.h_pl[j];      // conv2 may consume the twin through LDS-DMA
     if (j == 0) {
       // enc1: `in` holds the im2col patches, conv1 is a 1x1 GEMM over K = kp0
       p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1;
@@ -190,6 +205,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     }
   } else {
     p.in = ws + pl.h[j]; p.cin_p = k.cout_p; p.cin_real = k.cout;
+    p.in_pl = u->planes ? ws + pl.h_pl[j] : nullptr;
     p.w = k.w2; p.scale = k.s2; p.shift = k.h2; p.out = ws + pl.o[j]; p.relu = 1;
     p.ksize = 3; p.tap_lo = dot ? 4 : 0; p.tap_hi = dot ? 5 : 9;
     taps = dot ? 1 : 9;
@@ -202,14 +218,16 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     }
   }
   ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
-  if (!choice) c.prec = u->precision == DT_PREC_FP32 ? 0 : 1;
+  if (!choice) c.prec = u->precision == DT_PREC_FP32 ? 0 : (p.in_pl ? 2 : 1);
+  if (c.prec == 2 && !p.in_pl) c.prec = 1;
   if (taps != 9 || p.M > kSplitMaxRows) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
-  if (c.prec == 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
+  if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
   if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0) {
     // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
     p.add = nullptr;
-    p.in2 = in; p.w2 = c.prec == 1 ? k.wrb : k.wr; p.bias2 = k.hr; p.cin2_p = k.cin_p; p.cin2_real = k.cin;
+    p.in2 = in; p.w2 = c.prec >= 1 ? k.wrb : k.wr; p.bias2 = k.hr; p.cin2_p = k.cin_p; p.cin2_real = k.cin;
+    p.in2_pl = in_pl;
   }
   return true;
 }
@@ -245,13 +263,14 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
   const float *cur = ws + pl.a0;
   for (int j = 0; j < kBlocks; ++j) {
     if (j >= 1 && j <= 4) {        // encoder: pool the previous block's output
-      st = launch_maxpool(ws + pl.o[j - 1], ws + pl.pool[j - 1], Bt, pl.H[j - 1], pl.W[j - 1], u->blk[j - 1].cout_p, s);
+      st = launch_maxpool(ws + pl.o[j - 1], ws + pl.pool[j - 1], u->planes ? ws + pl.pool_pl[j - 1] : nullptr, Bt,
+                          pl.H[j - 1], pl.W[j - 1], u->blk[j - 1].cout_p, s);
       if (st) return st;
       cur = ws + pl.pool[j - 1];
     } else if (j >= 5) {           // decoder: upsample previous output, concat the matching encoder output
       const int skip = 8 - j;      // dec3<-enc4(3), dec2<-enc3(2), dec1<-enc2(1)
-      st = launch_upcat(ws + pl.o[j - 1], ws + pl.o[skip], ws + pl.cat[j - 5], Bt, pl.H[j - 1], pl.W[j - 1],
-                        u->blk[j - 1].cout_p, u->blk[skip].cout_p, s);
+      st = launch_upcat(ws + pl.o[j - 1], ws + pl.o[skip], ws + pl.cat[j - 5], u->planes ? ws + pl.cat_pl[j - 5] : nullptr,
+                        Bt, pl.H[j - 1], pl.W[j - 1], u->blk[j - 1].cout_p, u->blk[skip].cout_p, s);
       if (st) return st;
       cur = ws + pl.cat[j - 5];
     }
@@ -292,6 +311,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   if (!u) return (int)hipErrorOutOfMemory;
   u->desc = *desc;
   u->precision = DT_PREC_AUTO;
+  u->planes = true;
   const int C = desc->channels, D = desc->temb_dim;
   const int *d = desc->dims;
   for (int i = 0; i < 4; ++i) u->cp[i] = round_up(d[i], kChanPad);
@@ -337,6 +357,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   const size_t o_w1g = bump.take((size_t)D * D), o_b1g = bump.take(D), o_wc0 = bump.take(D), o_bc0 = bump.take(D);
   const size_t o_wc2 = bump.take((size_t)D * D), o_bc2 = bump.take(D), o_fr = bump.take(half);
   const size_t o_fw = bump.take((size_t)C * d[0]), o_fb = bump.take(C);
+  const size_t o_zero = bump.take(64);
   u->slab_floats = bump.off;
   hipError_t e = hipMalloc((void **)&u->slab, u->slab_floats * sizeof(float));
   if (e != hipSuccess) { delete u; return (int)e; }
@@ -388,6 +409,8 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   u->tw = TembWeights{S + o_fr, S + o_w1g, S + o_b1g, S + o_wc0, S + o_bc0, S + o_wc2, S + o_bc2, S + o_wt, S + o_bt,
                       D, half, tb};
   u->final_w = S + o_fw; u->final_b = S + o_fb;
+  u->zero_page = S + o_zero;
+  if (hipMemsetAsync(u->zero_page, 0, 256, s) != hipSuccess) { (void)hipFree(u->slab); delete u; return (int)hipGetLastError(); }
   *out = u;
   return DT_OK;
 }
@@ -450,8 +473,9 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       float best_ms = 1e30f;
       const bool can_fuse = slot == 2 && j > 0 && h->blk[j].has_res;
       const BlockW &kw = h->blk[j];
-      for (int prec = 0; prec <= 1; ++prec) {
-        if ((h->precision == DT_PREC_FP32 && prec == 1) || (h->precision == DT_PREC_SPLIT_BF16 && prec == 0)) continue;
+      for (int prec = 0; prec <= 2; ++prec) {
+        if ((h->precision == DT_PREC_FP32 && prec >= 1) || (h->precision == DT_PREC_SPLIT_BF16 && prec == 0)) continue;
+        if (prec == 2 && !p.in_pl) continue;
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
@@ -463,6 +487,8 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
             if (fuse) {
               q.add = nullptr; q.in2 = in; q.w2 = prec ? kw.wrb : kw.wr; q.bias2 = kw.hr; q.cin2_p = kw.cin_p;
               q.cin2_real = kw.cin;
+              q.in2_pl = (h->planes && j >= 1) ? ws + (j <= 4 ? pl.pool_pl[j - 1] : pl.cat_pl[j - 5]) : nullptr;
+              if (prec == 2 && !q.in2_pl) continue;
             }
             float ms_min = 1e30f;
             for (int rep = 0; rep < 5 && st == DT_OK; ++rep) {
@@ -500,6 +526,7 @@ int dt_unet_set_precision(dt_unet *h, int precision) {
   if (precision < DT_PREC_FP32 || precision > DT_PREC_AUTO) return DT_E_ARG;
   if (precision != h->precision) h->tuned.clear();
   h->precision = precision;
+  h->planes = precision != DT_PREC_FP32;      // changes the workspace size: re-query dt_unet_workspace_bytes
   return DT_OK;
 }
 
@@ -517,7 +544,7 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
     return DT_OK;
   }
   if (!p.bm || !p.bn) { const ConvChoice c = heuristic_choice(p.M, p.n_p, 1); p.bm = c.bm; p.bn = c.bn; }
-  *bm = p.bm; *bn = p.bn; *splits = p.splits; *prec = p.prec + (p.in2 ? 2 : 0); *tuned = t != nullptr;
+  *bm = p.bm; *bn = p.bn; *splits = p.splits; *prec = p.prec + (p.in2 ? 4 : 0); *tuned = t != nullptr;
   if (slot == 0) {   // folded into conv2?
     ConvParams c2;
     conv_slot(h, block, 2, &dummy, &dummy, pl, batch_total, &dummy, 1, t ? &t->c[block][2] : nullptr, c2);

@@ -111,6 +111,7 @@ class UNetHandle:
         """PREC_FP32 (exact fp32 MFMA), PREC_SPLIT_BF16 (3-plane bf16 split, 6 products) or PREC_AUTO."""
         check(self.lib.dt_unet_set_precision(self.h, int(mode)), "dt_unet_set_precision")
         self._tuned.clear()
+        self._ws.clear()                 # the workspace layout depends on whether plane twins are kept
 
     def autotune(self, batch_total, H, W):
         """Measure tile / tap-split candidates for this forward shape once and keep the fastest (dt_unet_autotune)."""
@@ -133,7 +134,7 @@ class UNetHandle:
                                                    ctypes.byref(sp), ctypes.byref(pr), ctypes.byref(tu)), "dt_unet_conv_choice")
                 if bm.value:
                     out.append((BLOCK_NAMES[j], ("skip", "conv1", "conv2")[slot], bm.value, bn.value, sp.value,
-                                ("fp32", "split-bf16", "fp32+skip", "split-bf16+skip")[pr.value], bool(tu.value)))
+                                ("fp32", "split-bf16", "split-bf16-dma", "?", "fp32+skip", "split-bf16+skip", "split-bf16-dma+skip")[pr.value], bool(tu.value)))
         return out
 
     def time_bias(self, t_values, cond_modes):

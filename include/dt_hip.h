@@ -111,8 +111,9 @@ int dt_unet_forward(const dt_unet *h, const float *x_dev, int B, int n_pass, int
  * Results are identical up to fp32 summation order (the split changes the grouping of the tap sum). */
 int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
-/* report hook: tile (bm x bn), tap split and arithmetic (0 fp32 MFMA, 1 split-bf16; +2 when the block's
- * 1x1 skip is folded into this conv2 launch) in use for block (0..7), slot (0 skip, 1 conv1, 2 conv2);
+/* report hook: tile (bm x bn), tap split and arithmetic (0 fp32 MFMA, 1 split-bf16 split in the consumer,
+ * 2 split-bf16 fed by LDS-DMA from pre-split plane tensors; +4 when the block's 1x1 skip is folded into
+ * this conv2 launch) in use for block (0..7), slot (0 skip, 1 conv1, 2 conv2);
  * bm = 0 means the slot has no launch of its own */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
                         int *splits, int *prec, int *tuned);
@@ -120,7 +121,9 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
 /* Convolution arithmetic.  Both variants are fp32-accurate: DT_PREC_FP32 uses the exact fp32 MFMA
  * (v_mfma_f32_32x32x2_f32); DT_PREC_SPLIT_BF16 splits every fp32 operand exactly into three bf16
  * planes and sums the six significant plane products on the bf16 matrix cores (fp32 accumulate; the
- * dropped cross terms are < 2^-25 relative).  DT_PREC_AUTO (default) lets the autotuner pick per layer. */
+ * dropped cross terms are < 2^-25 relative).  DT_PREC_AUTO (default) lets the autotuner pick per layer.
+ * Unless DT_PREC_FP32 is set, activation producers also emit exact bf16 plane twins (bigger workspace:
+ * call dt_unet_workspace_bytes again after changing the mode). */
 enum { DT_PREC_FP32 = 0, DT_PREC_SPLIT_BF16 = 1, DT_PREC_AUTO = 2 };
 int dt_unet_set_precision(dt_unet *h, int precision);
 
