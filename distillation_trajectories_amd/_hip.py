@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 
 COND_NONE, COND_ZERO, COND_ONE = 0, 1, 2
 RULE_ENGINE, RULE_PSAMPLE, RULE_MANAGER = 0, 1, 2
-PREC_FP32, PREC_SPLIT_BF16, PREC_AUTO = 0, 1, 2
+PREC_FP32, PREC_SPLIT_BF16, PREC_AUTO, PREC_AUTO_PLANES = 0, 1, 2, 3
 BT_COUNT, GT_COUNT, N_BLOCKS = 16, 9, 8
 ABI_VERSION = 1
 
@@ -38,6 +38,8 @@ SIGNATURES = {
     "dt_unet_conv_choice": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
                                     POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "dt_unet_set_precision": (c_int, [c_void_p, c_int]),
+    "dt_unet_time_conv": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_size_t, c_void_p, POINTER(c_float), POINTER(c_double)]),
     "dt_unet_debug_activation": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_int),
                                          POINTER(c_int), POINTER(c_int)]),
     "dt_cfg_update": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_float), c_int,

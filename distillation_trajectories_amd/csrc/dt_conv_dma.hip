@@ -14,7 +14,8 @@
 // out-of-image taps / rows beyond M read a zero page.  Pipeline: at the top of iteration i every wave
 // waits for its own DMAs of chunk i (vmcnt), the workgroup barrier makes all of them visible and also
 // retires every read of the other stage, then the DMAs of chunk i+1 are issued into that stage and fly
-// during the MFMAs of chunk i.  One barrier per chunk.
+// during the MFMAs of chunk i.  One barrier per chunk.  (Implemented as a 3-stage ring with the DMAs two
+// chunks ahead and a counted vmcnt, so an L2 miss has two chunk times to land.)
 #include "dt_conv_epilogue.h"
 
 namespace dt {
@@ -28,7 +29,8 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_bf16x6_dma_kernel(const Conv
   constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;            // bf16 elements per plane per stage
   constexpr int STAGE = 3 * (PLANE_A + PLANE_B);
   constexpr int GA = BM / 32, GB = BN / 32;                        // 32-row groups (one DMA instr per group and plane)
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
+  constexpr int NSTAGE = 3;                                       // ring: chunk i lives in stage i % 3
+  __shared__ __attribute__((aligned(16))) __bf16 lds[NSTAGE * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -114,13 +116,24 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_bf16x6_dma_kernel(const Conv
     }
   };
 
+  // Ring of three stages, DMAs two chunks ahead.  vmcnt counts this wave's outstanding DMA instructions in
+  // issue order, so "all but the youngest chunk's" = vmcnt(n_dma) retires chunk `it` while chunk it+1 stays
+  // in flight across the barrier (raw s_barrier: __syncthreads() would drain vmcnt to 0).
+  const int n_dma = (a_owner ? 3 : 0) + (b_owner ? 3 : 0);
   issue(0);
+  if (n_iter > 1) issue(1);
   for (int it = 0; it < n_iter; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of chunk `it` have landed
-    __syncthreads();                       // ... everyone's have, and all reads of the other stage are retired
-    if (it + 1 < n_iter) issue((it + 1) & 1);
+    if (it + 1 < n_iter) {
+      if (n_dma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (n_dma == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();          // chunk `it` is complete for every wave; reads of stage (it+2)%3 are retired
+    asm volatile("" ::: "memory");
+    if (it + 2 < n_iter) issue((it + 2) % NSTAGE);
     if (it == n_main && p.in2_pl) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
-    const __bf16 *A = lds + (it & 1) * STAGE, *B = A + 3 * PLANE_A;
+    const __bf16 *A = lds + (it % NSTAGE) * STAGE, *B = A + 3 * PLANE_A;
     bf16x8 fb[NI][3];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)

@@ -218,7 +218,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     }
   }
   ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
-  if (!choice) c.prec = u->precision == DT_PREC_FP32 ? 0 : (p.in_pl ? 2 : 1);
+  if (!choice) c.prec = u->precision == DT_PREC_FP32 ? 0 : (p.in_pl ? 2 : 1);   // untuned default per mode
   if (c.prec == 2 && !p.in_pl) c.prec = 1;
   if (taps != 9 || p.M > kSplitMaxRows) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
@@ -311,7 +311,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   if (!u) return (int)hipErrorOutOfMemory;
   u->desc = *desc;
   u->precision = DT_PREC_AUTO;
-  u->planes = true;
+  u->planes = false;
   const int C = desc->channels, D = desc->temb_dim;
   const int *d = desc->dims;
   for (int i = 0; i < 4; ++i) u->cp[i] = round_up(d[i], kChanPad);
@@ -521,12 +521,44 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
   return DT_OK;
 }
 
+/* tuning / profiling aid: average milliseconds (HIP events, synchronises) of ONE convolution launch of a
+ * forward shape under an explicit (tile, split, arithmetic, fuse) choice, plus its algorithmic FLOPs */
+int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn, int splits,
+                      int prec, int fuse, int reps, void *workspace, size_t ws_bytes, void *stream, float *ms,
+                      double *flops) {
+  if (!h || !workspace || !ms || !flops) return DT_E_NULL;
+  if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || reps < 1) return DT_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const Plan pl = make_plan(h, batch_total, H, W);
+  if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
+  float *ws = (float *)workspace;
+  const float *in = block == 0 ? ws + pl.a0 : (block <= 4 ? ws + pl.pool[block - 1] : ws + pl.cat[block - 5]);
+  const ConvChoice c{bm, bn, splits, prec, fuse};
+  ConvParams p;
+  if (!conv_slot(h, block, slot, in, ws, pl, batch_total, h->slab, batch_total, &c, p)) { *ms = 0.f; *flops = 0.0; return DT_OK; }
+  *flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));
+  hipEvent_t e0, e1;
+  DT_HIP_TRY(hipEventCreate(&e0));
+  DT_HIP_TRY(hipEventCreate(&e1));
+  int st = launch_conv(p, s);   // warm
+  (void)hipEventRecord(e0, s);
+  for (int r = 0; r < reps && st == DT_OK; ++r) st = launch_conv(p, s);
+  (void)hipEventRecord(e1, s);
+  if (hipEventSynchronize(e1) != hipSuccess) st = (int)hipGetLastError();
+  float t = 0.f;
+  (void)hipEventElapsedTime(&t, e0, e1);
+  *ms = t / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return st;
+}
+
 int dt_unet_set_precision(dt_unet *h, int precision) {
   if (!h) return DT_E_NULL;
-  if (precision < DT_PREC_FP32 || precision > DT_PREC_AUTO) return DT_E_ARG;
+  if (precision < DT_PREC_FP32 || precision > DT_PREC_AUTO_PLANES) return DT_E_ARG;
   if (precision != h->precision) h->tuned.clear();
   h->precision = precision;
-  h->planes = precision != DT_PREC_FP32;      // changes the workspace size: re-query dt_unet_workspace_bytes
+  h->planes = precision == DT_PREC_AUTO_PLANES;   // changes the workspace size: re-query dt_unet_workspace_bytes
   return DT_OK;
 }
 

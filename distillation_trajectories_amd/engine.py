@@ -68,17 +68,17 @@ class UNetHandle:
         self.h = h
         self.tb_stride = self.lib.dt_unet_time_bias_stride(self.h)
         mode = os.environ.get("DT_PRECISION", "auto")
-        check(self.lib.dt_unet_set_precision(self.h, {"fp32": 0, "split-bf16": 1, "auto": 2}[mode]), "dt_unet_set_precision")
+        check(self.lib.dt_unet_set_precision(self.h, {"fp32": 0, "split-bf16": 1, "auto": 2, "auto-planes": 3}[mode]), "dt_unet_set_precision")
         self._ws = {}
         self._tuned = set()
 
     def __del__(self):
-        h, self.h = getattr(self, "h", None), None
-        if h and not sys.is_finalizing():        # at interpreter exit the HIP runtime may already be gone
-            try:
+        try:
+            h, self.h = getattr(self, "h", None), None
+            if h and not sys.is_finalizing():    # at interpreter exit the HIP runtime may already be gone
                 self.lib.dt_unet_destroy(h)
-            except Exception:
-                pass
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ caching per nn.Module
     @staticmethod
@@ -108,7 +108,8 @@ class UNetHandle:
         return ws
 
     def set_precision(self, mode):
-        """PREC_FP32 (exact fp32 MFMA), PREC_SPLIT_BF16 (3-plane bf16 split, 6 products) or PREC_AUTO."""
+        """PREC_FP32 (exact fp32 MFMA), PREC_SPLIT_BF16 (3-plane bf16 split, 6 products), PREC_AUTO, or
+        PREC_AUTO_PLANES (AUTO + pre-split plane twins feeding the LDS-DMA kernel)."""
         check(self.lib.dt_unet_set_precision(self.h, int(mode)), "dt_unet_set_precision")
         self._tuned.clear()
         self._ws.clear()                 # the workspace layout depends on whether plane twins are kept
