@@ -34,6 +34,9 @@ def all_gather_rows(local, counts, dim):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
+    if dist.get_backend() != "nccl" and local.is_cuda:
+        # CPU rehearsal backends (gloo): exchange on the host, hand the result back on the device
+        return all_gather_rows(local.cpu(), counts, dim).to(local.device)
     pad = max(counts)
     shape = list(local.shape)
     shape[dim] = pad
