@@ -51,6 +51,8 @@ SIGNATURES = {
     "dt_traj_wasserstein": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                     c_void_p]),
     "dt_traj_resampled_distance": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dt_pair_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dt_traj_sample_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dt_profile_begin": (c_int, []),
     "dt_profile_end": (c_int, []),
     "dt_profile_class_count": (c_int, []),

@@ -134,6 +134,34 @@ def pair_metrics_device(X, Y, pixels, seeds=None):
     return [engine.metrics_from_sums(sums[b], w1[b], n, n, pixels, E) for b in range(B)]
 
 
+def average_sample_trajectories(teacher_model, student_model, config, guidance_scales, num_samples, base_seed=42):
+    """Per-guidance-scale trajectories averaged over samples, as scripts/analysis/analyze_trajectories.py
+    :437-486 builds them before its PCA plots: sample i uses seed base_seed+i; returns
+    (teacher, student) dicts {gs: [T+1 CPU tensors [1,C,H,W]]}.  One batched launch sequence per model
+    and CFG plan, then a device mean over the sample axis (dt_traj_sample_mean)."""
+    device = next(teacher_model.parameters()).device
+    teacher_model.eval(); student_model.eval()
+    C, H, T, S = config.channels, config.image_size, config.timesteps, num_samples
+    state = torch.get_rng_state()
+    table = noise_table(base_seed, S + T - 1, (1, C, H, H)).reshape(S + T - 1, -1).to(device)
+    torch.set_rng_state(state)
+    out = []
+    for model in (teacher_model, student_model):
+        grid = sample_grid(engine.UNetHandle.for_module(model), table, 0, S, T, list(guidance_scales), H, H)
+        avg = {}
+        for gs in guidance_scales:
+            mean = engine.device_sample_mean(grid[gs].contiguous()).cpu().reshape(T + 1, 1, C, H, H)
+            avg[gs] = [mean[i].clone() for i in range(T + 1)]
+        out.append(avg)
+    # leave the global generators as the reference's last generate_trajectory call does
+    last = base_seed + S - 1
+    torch.manual_seed(last + 1 if T > 1 else last)
+    np.random.seed(last + 1 if T > 1 else last)
+    if T > 1:
+        torch.randn(1, C, H, H)
+    return out[0], out[1]
+
+
 def compare_trajectories(teacher_model, student_model, config, guidance_scales=[1.0, 3.0, 5.0], size_factor=1.0,
                          num_samples=3):
     """Teacher-vs-student metric averages per guidance scale (reference :117-180).

@@ -84,6 +84,71 @@ int launch_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Same-index statistics of two state sequences (evaluation/metrics.py:118-183 compute_trajectory_divergence,
+// analysis/noise_prediction/noise_analysis.py:43-85 calculate_noise_metrics):
+// out[b][i] = { sum (x-y)^2, sum |x-y|, sum x*y, sum x^2, sum y^2 } over the E coordinates of state i of pair b.
+__global__ __launch_bounds__(256) void pair_stats_kernel(const float *__restrict__ X, const float *__restrict__ Y, int B,
+                                                         int E, double *__restrict__ out, int n) {
+  __shared__ double sm[20];
+  const int b = blockIdx.x, i = blockIdx.y;
+  const float4 *x = reinterpret_cast<const float4 *>(X + ((size_t)i * B + b) * E);
+  const float4 *y = reinterpret_cast<const float4 *>(Y + ((size_t)i * B + b) * E);
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int e = threadIdx.x; e < E / 4; e += 256) {
+    const float4 a = x[e], c = y[e];
+    const float av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = av[k] - cv[k];          // fp32 difference, as torch forms it
+      acc[0] += (double)d * (double)d;
+      acc[1] += fabs((double)d);
+      acc[2] += (double)av[k] * (double)cv[k];
+      acc[3] += (double)av[k] * (double)av[k];
+      acc[4] += (double)cv[k] * (double)cv[k];
+    }
+  }
+  block_sum<5>(acc, sm);
+  if (threadIdx.x == 0) {
+    double *o = out + ((size_t)b * n + i) * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = acc[k];
+  }
+}
+
+int launch_pair_stats(const float *X, const float *Y, int n, int B, int E, double *out, hipStream_t s) {
+  if (!X || !Y || !out) return DT_E_NULL;
+  if (n < 1 || B < 1 || E < 4 || E % 4 || n > 65535) return DT_E_SHAPE;
+  ProfileScope prof(KC_METRICS, 0.0, 8.0 * B * E * (double)n, s);
+  pair_stats_kernel<<<dim3(B, n), 256, 0, s>>>(X, Y, B, E, out, n);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// per-timestep mean over the B samples of a trajectory tensor [n][B][E] -> [n][E]
+// (scripts/analysis/analyze_trajectories.py:467-486 averages sample trajectories before the PCA plots)
+__global__ __launch_bounds__(256) void sample_mean_kernel(const float *__restrict__ traj, int B, int E,
+                                                          float *__restrict__ out, size_t total) {
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t i = idx / E, e = idx - i * E;
+    const float *p = traj + i * (size_t)B * E + e;
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b) acc += (double)p[(size_t)b * E];
+    out[idx] = (float)(acc / (double)B);
+  }
+}
+
+int launch_sample_mean(const float *traj, int n, int B, int E, float *out, hipStream_t s) {
+  if (!traj || !out) return DT_E_NULL;
+  if (n < 1 || B < 1 || E < 1) return DT_E_SHAPE;
+  const size_t total = (size_t)n * E;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  ProfileScope prof(KC_METRICS, 0.0, 4.0 * total * (B + 1.0), s);
+  sample_mean_kernel<<<blocks, 256, 0, s>>>(traj, B, E, out, total);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // W1 between the empirical distributions of the coordinates of X_i and Y_i (equal sample sizes):
 // mean_k |u_(k) - v_(k)| over the order statistics.  Both samples are bitonic-sorted in LDS
 // (padded to a power of two with +inf, which sorts to the tail of BOTH arrays and cancels).

@@ -22,6 +22,8 @@ int launch_wasserstein(const float *X, const float *Y, int n, int B, int E, cons
                        const int32_t *index_row, int n_idx, double *out, hipStream_t s);
 int launch_resampled_distance(const float *L, const float *S, int n_long, int n_short, int B, int E, double *out,
                               hipStream_t s);
+int launch_pair_stats(const float *X, const float *Y, int n, int B, int E, double *out, hipStream_t s);
+int launch_sample_mean(const float *traj, int n, int B, int E, float *out, hipStream_t s);
 }  // namespace dt
 
 using namespace dt;
@@ -660,6 +662,14 @@ int dt_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, int E
 int dt_traj_wasserstein(const float *X, const float *Y, int n, int B, int E, const int32_t *index,
                         const int32_t *index_row, int n_idx, double *out, void *stream) {
   return launch_wasserstein(X, Y, n, B, E, index, index_row, n_idx, out, (hipStream_t)stream);
+}
+
+int dt_pair_stats(const float *X, const float *Y, int n, int B, int E, double *out, void *stream) {
+  return launch_pair_stats(X, Y, n, B, E, out, (hipStream_t)stream);
+}
+
+int dt_traj_sample_mean(const float *traj, int n, int B, int E, float *out, void *stream) {
+  return launch_sample_mean(traj, n, B, E, out, (hipStream_t)stream);
 }
 
 int dt_traj_resampled_distance(const float *L, const float *S, int n_long, int n_short, int B, int E, double *out,

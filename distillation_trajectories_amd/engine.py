@@ -272,6 +272,28 @@ def device_wasserstein(X, Y, index=None, index_row=None):
     return out
 
 
+def device_pair_stats(X, Y):
+    """float64 [B, n, 5] = {sum (x-y)^2, sum |x-y|, sum xy, sum x^2, sum y^2} for X, Y [n, B, E] (dt_pair_stats)."""
+    lib = _hip.load()
+    _require_cuda(X, "X"); _require_cuda(Y, "Y")
+    n, B, E = X.shape
+    out = torch.empty(B, n, 5, dtype=torch.float64, device=X.device)
+    with torch.cuda.device(X.device):
+        check(lib.dt_pair_stats(ptr(X), ptr(Y), n, B, E, ptr(out), stream_ptr()), "dt_pair_stats")
+    return out
+
+
+def device_sample_mean(traj):
+    """fp32 [n, E]: mean over the B samples of traj [n, B, E] (dt_traj_sample_mean)."""
+    lib = _hip.load()
+    _require_cuda(traj, "traj")
+    n, B, E = traj.shape
+    out = torch.empty(n, E, dtype=torch.float32, device=traj.device)
+    with torch.cuda.device(traj.device):
+        check(lib.dt_traj_sample_mean(ptr(traj), n, B, E, ptr(out), stream_ptr()), "dt_traj_sample_mean")
+    return out
+
+
 def device_resampled_distance(longer, shorter):
     lib = _hip.load()
     nl, B, E = longer.shape

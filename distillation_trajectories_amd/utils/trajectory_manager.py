@@ -58,29 +58,73 @@ class TrajectoryManager:
         steps = float(self.config.teacher_steps)        # the student also divides by teacher_steps
         return [(beta, sqrt_alpha, 0.1 * (float(t) / steps)) for t in indices]
 
-    def _run(self, model, x0, indices):
-        """[(x[1,C,H,W] on self.device, t)] for one model: record, predict, update while t > 0 (:100-112)."""
+    def _run_states(self, model, x0, indices, z):
+        """Device states [n_upd+1, S, E] of one model for S start images x0[S,C,H,W]: record, predict, update
+        while t > 0 (reference :100-112).  z[n_upd, S, E] holds the step noise in draw order."""
         h = engine.UNetHandle.for_module(model)
-        _, C, H, W = x0.shape
+        S, C, H, W = x0.shape
         E = C * H * W
-        n = len(indices)
         n_upd = sum(1 for t in indices if t > 0)        # every visited t except a trailing 0 is followed by an update
         upd = indices[:n_upd]
-        zs = [torch.randn(1, C, H, W) for _ in upd]     # one CPU-generator draw per update, in order
-        traj = torch.empty(n_upd + 1, 1, E, dtype=torch.float32, device=self.device)
-        traj[0].copy_(x0.reshape(1, E))
+        traj = torch.empty(n_upd + 1, S, E, dtype=torch.float32, device=self.device)
+        traj[0].copy_(x0.reshape(S, E))
         if n_upd:
-            z = torch.stack(zs).reshape(-1, E).to(self.device)
             tb = h.time_bias(upd, [COND_NONE] * n_upd)
-            h.sample(RULE_MANAGER, traj, H, W, tb, 1, self._manager_coefficients(upd), [True] * n_upd, z=z,
-                     z_shift=list(range(n_upd)))
-        states = traj.reshape(n_upd + 1, 1, C, H, W)
-        out = [(states[i].clone(), t) for i, t in enumerate(indices[: n_upd + 1])]
+            h.sample(RULE_MANAGER, traj, H, W, tb, 1, self._manager_coefficients(upd), [True] * n_upd,
+                     z=z.reshape(-1, E).to(self.device), z_shift=[k * S for k in range(n_upd)])
+        return traj, n_upd
+
+    def _as_pairs(self, states, n_upd, indices, sample, shape):
+        """[(x[1,C,H,W] on self.device, t)] of one sample from the batched device states."""
+        C, H, W = shape
+        out = [(states[i, sample].reshape(1, C, H, W).clone(), t) for i, t in enumerate(indices[: n_upd + 1])]
         # indices after the first t == 0 (never produced by timestep_list) would repeat the last state
         for t in indices[n_upd + 1:]:
-            out.append((states[n_upd].clone(), t))
-        assert len(out) == n
+            out.append((states[n_upd, sample].reshape(1, C, H, W).clone(), t))
         return out
+
+    def _run(self, model, x0, indices):
+        """[(x[1,C,H,W] on self.device, t)] for one model and one start image; draws the step noise from
+        the CPU generator in the reference's order (one draw per update)."""
+        _, C, H, W = x0.shape
+        n_upd = sum(1 for t in indices if t > 0)
+        zs = [torch.randn(1, C, H, W) for _ in range(n_upd)]
+        z = torch.stack(zs).reshape(n_upd, 1, C * H * W) if zs else None
+        states, n_upd = self._run_states(model, x0, indices, z)
+        return self._as_pairs(states, n_upd, indices, 0, (C, H, W))
+
+    def generate_trajectories_batched(self, seeds):
+        """[(teacher_trajectory, student_trajectory)] for many seeds with ONE batched loop per model
+        (what generate_and_save_trajectories uses): per seed the CPU generator is re-seeded, x_T drawn,
+        then one draw per update -- the student re-seeds and therefore reuses the same stream (:114-116)."""
+        cfg = self.config
+        size = self._student_size()
+        if size != cfg.image_size:
+            return [self.generate_trajectory(seed=s) for s in seeds]     # different student resolution: no shared noise
+        self.teacher_model.eval()
+        self.student_model.eval()
+        shape = (cfg.channels, cfg.image_size, cfg.image_size)
+        t_idx = timestep_list(cfg.sample_steps, cfg.teacher_steps)
+        s_idx = timestep_list(cfg.sample_steps, cfg.student_steps)
+        n_t, n_s = sum(1 for t in t_idx if t > 0), sum(1 for t in s_idx if t > 0)
+        x0, z = [], []
+        for seed in seeds:
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            x0.append(torch.randn(1, *shape))
+            z.append(torch.stack([torch.randn(1, *shape) for _ in range(max(n_t, n_s))]) if max(n_t, n_s) else None)
+        x0 = torch.cat(x0)
+        zz = torch.stack(z, dim=1).reshape(max(n_t, n_s), len(seeds), -1) if max(n_t, n_s) else None
+        t_states, _ = self._run_states(self.teacher_model, x0, t_idx, None if zz is None else zz[:n_t])
+        s_states, _ = self._run_states(self.student_model, x0, s_idx, None if zz is None else zz[:n_s])
+        # global generators as after the reference's last per-seed call (student pass of the last seed)
+        last = seeds[-1]
+        torch.manual_seed(last)
+        np.random.seed(last)
+        for _ in range(1 + n_s):
+            torch.randn(1, *shape)
+        return [(self._as_pairs(t_states, n_t, t_idx, i, shape), self._as_pairs(s_states, n_s, s_idx, i, shape))
+                for i in range(len(seeds))]
 
     def _student_size(self):
         return getattr(self.student_model, "image_size", self.config.image_size)
@@ -157,10 +201,18 @@ class TrajectoryManager:
         use_fixed = self.fixed_samples is not None and num_samples <= len(self.fixed_samples)
         if use_fixed:
             print(f"Using {num_samples} fixed samples for consistent comparison")
+        batched = None
+        if not use_fixed:
+            try:      # all seeds in one device-resident batch; per-seed fallback keeps the reference's error behaviour
+                batched = self.generate_trajectories_batched(list(range(num_samples)))
+            except Exception as e:
+                print(f"Batched trajectory generation failed ({e}); generating one by one")
         for i in range(num_samples):
             try:
                 if use_fixed:
                     pair = self.generate_trajectory_from_sample(self.fixed_samples[:num_samples][i], i)
+                elif batched is not None:
+                    pair = batched[i]
                 else:
                     pair = self.generate_trajectory(seed=i)
             except Exception as e:

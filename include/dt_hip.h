@@ -189,6 +189,15 @@ int dt_traj_wasserstein(const float *teacher_dev, const float *student_dev, int 
 int dt_traj_resampled_distance(const float *long_dev, const float *short_dev, int n_long, int n_short,
                                int B, int E, double *out_dist_dev, void *stream);
 
+/* Next-row reductions.
+ * dt_pair_stats: evaluation/metrics.py:118-183 (compute_trajectory_divergence) and
+ * analysis/noise_prediction/noise_analysis.py:43-85 (calculate_noise_metrics): for state i of pair b,
+ * out[b][i] = { sum (x-y)^2, sum |x-y|, sum x*y, sum x^2, sum y^2 } in float64.  X, Y are [n][B][E].
+ * dt_traj_sample_mean: scripts/analysis/analyze_trajectories.py:467-486: mean over the B samples of a
+ * trajectory tensor [n][B][E] -> out[n][E] (float64 accumulation, fp32 result). */
+int dt_pair_stats(const float *x_dev, const float *y_dev, int n, int B, int E, double *out_dev, void *stream);
+int dt_traj_sample_mean(const float *traj_dev, int n, int B, int E, float *out_dev, void *stream);
+
 /* -------------------------------------------------------------- profiling ---
  * Optional per-launch timing for the benchmark's roofline line: between dt_profile_begin() and
  * dt_profile_end() every kernel launch of this library is bracketed by two hipEventRecord calls on

@@ -167,3 +167,30 @@ def transform_metrics(path_length_similarity, trajectory_mse, directional_consis
         "mean_directional_consistency": np.abs(directional_consistency),
         "distribution_similarity": dist,
     }
+
+
+def trajectory_divergence(trajectory1, trajectory2):
+    """evaluation/metrics.py:118-183 (entries are (image, timestep) pairs)."""
+    from sklearn.metrics.pairwise import cosine_similarity
+    im1 = [item[0] for item in trajectory1]
+    im2 = [item[0] for item in trajectory2]
+    distances = [torch.norm(a.flatten() - b.flatten()).item() for a, b in zip(im1, im2)]
+    sims = [cosine_similarity(a.flatten().cpu().numpy().reshape(1, -1), b.flatten().cpu().numpy().reshape(1, -1))[0, 0]
+            for a, b in zip(im1, im2)]
+    l1 = l2 = 0
+    for i in range(1, len(im1)):
+        l1 += torch.norm(im1[i] - im1[i - 1]).item()
+    for i in range(1, len(im2)):
+        l2 += torch.norm(im2[i] - im2[i - 1]).item()
+    return {"distances": distances, "similarities": sims, "avg_distance": np.mean(distances),
+            "max_distance": np.max(distances), "avg_similarity": np.mean(sims), "min_similarity": np.min(sims),
+            "length_ratio": l2 / l1 if l1 > 0 else float("inf")}
+
+
+def noise_metrics(teacher_noise, student_noise):
+    """analysis/noise_prediction/noise_analysis.py:43-85 for equal shapes."""
+    mse = torch.mean((teacher_noise - student_noise) ** 2).item()
+    mae = torch.mean(torch.abs(teacher_noise - student_noise)).item()
+    tf = torch.nn.functional.normalize(teacher_noise.view(teacher_noise.size(0), -1), p=2, dim=1)
+    sf = torch.nn.functional.normalize(student_noise.view(student_noise.size(0), -1), p=2, dim=1)
+    return {"mse": mse, "mae": mae, "cosine_similarity": torch.mean(torch.sum(tf * sf, dim=1)).item()}

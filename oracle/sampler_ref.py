@@ -190,3 +190,20 @@ def compare_trajectories(teacher_fn, student_fn, cfg, guidance_scales=(1.0, 3.0,
             if isinstance(v, (int, float)) and not isinstance(v, bool):
                 avg[gs][k] = sum(m[k] for m in per_gs[gs]) / len(per_gs[gs])
     return {"teacher_metrics": avg, "student_metrics": {gs: dict(v) for gs, v in avg.items()}}
+
+
+def average_sample_trajectories(teacher_fn, student_fn, cfg, guidance_scales, num_samples, base_seed=42):
+    """scripts/analysis/analyze_trajectories.py:437-486: per-scale trajectories averaged over samples."""
+    per = [{gs: [] for gs in guidance_scales} for _ in range(2)]
+    for i in range(num_samples):
+        seed = base_seed + i
+        torch.manual_seed(seed); np.random.seed(seed)
+        noise = torch.randn(1, cfg.channels, cfg.image_size, cfg.image_size)
+        for gs in guidance_scales:
+            for k, fn in enumerate((teacher_fn, student_fn)):
+                per[k][gs].append(generate_trajectory(fn, noise, cfg.timesteps, seed=seed, guidance_scale=gs))
+    out = []
+    for k in range(2):
+        out.append({gs: [torch.mean(torch.stack([tr[t] for tr in per[k][gs]]), dim=0) for t in range(len(per[k][gs][0]))]
+                    for gs in guidance_scales})
+    return out[0], out[1]

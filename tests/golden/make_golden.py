@@ -59,6 +59,9 @@ from analysis.metrics.time_dependent import analyze_time_dependent_distances as 
 from utils.trajectory_manager import TrajectoryManager as RefManager  # noqa: E402
 from utils.metric_transformations import transform_metrics as ref_transform  # noqa: E402
 
+from evaluation.metrics import compute_trajectory_divergence as ref_divergence      # noqa: E402
+from analysis.noise_prediction.noise_analysis import calculate_noise_metrics as ref_noise_metrics  # noqa: E402
+
 from distillation_trajectories_amd.synthetic import make_model, state_dict_digest, seeded_noise  # noqa: E402
 
 quiet = lambda: contextlib.redirect_stdout(io.StringIO())   # noqa: E731
@@ -272,6 +275,39 @@ def main():
     # ---------------------------------------------------------------- (9) transform_metrics
     tcases = [(0.5, 0.3, -0.7, 0.6), (0.69, -1.5, 0.2, 0.9), (0.1, float("nan"), 1.0, 0.0), (0.0, 5.0, -1.0, 3.0)]
     out_json["transform_cases"] = [dict(args=list(a), result=jsonable(ref_transform(*a))) for a in tcases]
+
+    # ---------------------------------------------------------------- (10) SURVEY §8f next rows
+    # trajectory divergence on the stored manager pairs (equal and unequal lengths)
+    div = []
+    for c in mg:
+        tt = [(torch.from_numpy(x), t) for x, t in zip(out_npz[c["key"] + "_teacher"], c["teacher_t"])]
+        st = [(torch.from_numpy(x), t) for x, t in zip(out_npz[c["key"] + "_student"], c["student_t"])]
+        div.append(dict(key=c["key"], result=jsonable(ref_divergence(tt, st))))
+    out_json["divergence_cases"] = div
+    # noise-prediction metrics on random prediction batches
+    g = torch.Generator().manual_seed(77)
+    tn = torch.randn(5, 3, 16, 16, generator=g)
+    sn = tn + 0.3 * torch.randn(5, 3, 16, 16, generator=g)
+    out_npz["noise_teacher"], out_npz["noise_student"] = tn.numpy(), sn.numpy()
+    out_json["noise_metric_case"] = jsonable(ref_noise_metrics(tn, sn))
+    # sample-averaged trajectories exactly as scripts/analysis/analyze_trajectories.py:437-486 builds them
+    c = cfg(timesteps=12)
+    scales, S, base_seed = [1.0, 3.0], 3, 42
+    per = [{gs: [] for gs in scales} for _ in range(2)]
+    for i in range(S):
+        seed = base_seed + i
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        noise = torch.randn(1, c.channels, c.image_size, c.image_size)
+        for gs in scales:
+            for k, model in enumerate((mdl[0.2], mdl[0.01])):
+                with quiet():
+                    per[k][gs].append(ref_engine.generate_trajectory(model, noise, c.timesteps, torch.device("cpu"), seed=seed, guidance_scale=gs))
+    for k, who in enumerate(("teacher", "student")):
+        for gs in scales:
+            avg = [torch.mean(torch.stack([tr[t] for tr in per[k][gs]]), dim=0) for t in range(len(per[k][gs][0]))]
+            out_npz[f"avg_{who}_{gs}"] = torch.stack(avg).numpy()
+    out_json["average_case"] = dict(teacher_sf=0.2, student_sf=0.01, T=12, guidance_scales=scales, num_samples=S, base_seed=base_seed)
 
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out_npz)
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as f:

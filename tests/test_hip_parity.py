@@ -413,3 +413,93 @@ def test_conv_arithmetic_accuracy_vs_float64(models):
     assert max(errs.values()) < 2e-6, errs
     assert errs["split-bf16-dma"] <= 2.0 * errs["fp32"] + 1e-7, errs
     assert errs["split-bf16"] <= 2.0 * errs["fp32"] + 1e-7, errs
+
+
+# ------------------------------------------------------------------ remaining API corners and SURVEY §8f next rows
+def test_p_sample_per_sample_timesteps(gpu_models):
+    """p_sample with a different t per batch row (the general form of utils/diffusion.py:102)."""
+    from distillation_trajectories_amd.utils.diffusion import get_diffusion_params, p_sample
+    m = gpu_models(0.01)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    x = seeded_noise(15, (4, 3, 16, 16))
+    t = torch.tensor([3, 40, 3, 17])
+    torch.manual_seed(21)
+    got = p_sample(m, x.to(DEV), t.to(DEV), 5, get_diffusion_params(50), guidance_scale=2.0)
+    torch.manual_seed(21)
+    with torch.no_grad():
+        want = sampler_ref.p_sample(lambda a, b, c: unet_ref.unet_forward(sd, a, b, c), x, t, 5, sampler_ref.diffusion_params(50), 2.0)
+    assert_close(got.cpu().numpy(), want.numpy(), what="per-sample t")
+
+
+def test_generate_trajectory_batched_without_cfg(gpu_models):
+    """B > 1 is legal in the reference when no CFG branch is taken (trajectory_engine.py:83)."""
+    from distillation_trajectories_amd.analysis.trajectory_engine import generate_trajectory
+    m = gpu_models(0.2)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    noise = seeded_noise(3, (3, 3, 16, 16))
+    got = torch.stack(generate_trajectory(m, noise, 10, torch.device(DEV), seed=9, guidance_scale=1.0))
+    with torch.no_grad():
+        want = torch.stack(sampler_ref.generate_trajectory(lambda a, b, c: unet_ref.unet_forward(sd, a, b, c), noise, 10, seed=9,
+                                                           guidance_scale=1.0))
+    assert_close(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-4, what="B=3 engine")
+
+
+def test_manager_fixed_samples_and_batched_generation(gpu_models, tmp_path):
+    from distillation_trajectories_amd.utils.trajectory_manager import TrajectoryManager
+    cfg = Config()
+    cfg.image_size, cfg.sample_steps, cfg.teacher_steps, cfg.student_steps = 16, 40, 8, 4
+    cfg.trajectory_dir = str(tmp_path / "t")
+    teacher, student = gpu_models(0.2), gpu_models(0.01)
+    sds = [{k: v.cpu() for k, v in mm.state_dict().items()} for mm in (teacher, student)]
+    fns = [lambda a, b, c, sd=sd: unet_ref.unet_forward(sd, a, b, c) for sd in sds]
+    man = TrajectoryManager(teacher, student, cfg, size_factor=0.01)
+    # batched generation over seeds 0..3 equals the reference's one-by-one loop (oracle)
+    pairs = man.generate_trajectories_batched([0, 1, 2, 3])
+    state_after = torch.get_rng_state()
+    for seed, (tt, st) in enumerate(pairs):
+        with torch.no_grad():
+            wt, ws = sampler_ref.manager_generate(fns[0], fns[1], cfg, seed=seed)
+        assert [t for _, t in tt] == [t for _, t in wt] and [t for _, t in st] == [t for _, t in ws]
+        assert_close(torch.stack([x.cpu() for x, _ in tt]).numpy(), torch.stack([x for x, _ in wt]).numpy(), rtol=1e-4, atol=1e-4)
+        assert_close(torch.stack([x.cpu() for x, _ in st]).numpy(), torch.stack([x for x, _ in ws]).numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(state_after, torch.get_rng_state())          # same generator state as the per-seed loop leaves
+    # fixed start samples (reference :265-387): noise continues from the seeded generator, student not re-seeded
+    fixed = seeded_noise(99, (2, 1, 3, 16, 16))
+    man2 = TrajectoryManager(teacher, student, cfg, size_factor=0.01, fixed_samples=fixed)
+    tt, st = man2.generate_trajectory_from_sample(fixed[1], seed=1)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        wt = sampler_ref.manager_trajectory(fns[0], fixed[1], sampler_ref.manager_indices(40, 8), 8)
+        ws = sampler_ref.manager_trajectory(fns[1], fixed[1], sampler_ref.manager_indices(40, 4), 8)
+    assert_close(torch.stack([x.cpu() for x, _ in tt]).numpy(), torch.stack([x for x, _ in wt]).numpy(), rtol=1e-4, atol=1e-4)
+    assert_close(torch.stack([x.cpu() for x, _ in st]).numpy(), torch.stack([x for x, _ in ws]).numpy(), rtol=1e-4, atol=1e-4)
+    assert len(man2.generate_and_save_trajectories(2)) == 2
+
+
+def test_next_rows_divergence_noise_metrics_average(golden, gpu_models):
+    from distillation_trajectories_amd.analysis.noise_prediction.noise_analysis import calculate_noise_metrics, predict_noise
+    from distillation_trajectories_amd.analysis.trajectory_engine import average_sample_trajectories
+    from distillation_trajectories_amd.evaluation.metrics import compute_trajectory_divergence
+    arrays, meta = golden
+    for c, d in zip(meta["manager_cases"], meta["divergence_cases"]):
+        tt = [(torch.from_numpy(x), t) for x, t in zip(arrays[c["key"] + "_teacher"], c["teacher_t"])]
+        st = [(torch.from_numpy(x), t) for x, t in zip(arrays[c["key"] + "_student"], c["student_t"])]
+        _check_metrics(compute_trajectory_divergence(tt, st), d["result"], rel=2e-5)
+    got = calculate_noise_metrics(torch.from_numpy(arrays["noise_teacher"]), torch.from_numpy(arrays["noise_student"]))
+    _check_metrics(got, meta["noise_metric_case"], rel=2e-5)
+    assert all(isinstance(v, float) for v in got.values())
+    m = gpu_models(0.2)
+    x = seeded_noise(4, (3, 3, 16, 16)).to(DEV)
+    eps = predict_noise(m, x, torch.tensor([7, 7, 7], device=DEV), torch.device(DEV))
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        assert_close(eps.cpu().numpy(), unet_ref.unet_forward(sd, x.cpu(), torch.tensor([7, 7, 7])).numpy(), what="predict_noise")
+    c = meta["average_case"]
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = 16, c["T"]
+    ta, sa = average_sample_trajectories(gpu_models(c["teacher_sf"]), gpu_models(c["student_sf"]), cfg, c["guidance_scales"],
+                                         c["num_samples"], base_seed=c["base_seed"])
+    for gs in c["guidance_scales"]:
+        assert ta[gs][0].shape == (1, 3, 16, 16) and len(ta[gs]) == c["T"] + 1
+        assert_close(torch.stack(ta[gs]).numpy(), arrays[f"avg_teacher_{gs}"], rtol=1e-4, atol=1e-4, what=f"avg teacher {gs}")
+        assert_close(torch.stack(sa[gs]).numpy(), arrays[f"avg_student_{gs}"], rtol=1e-4, atol=1e-4, what=f"avg student {gs}")

@@ -173,3 +173,26 @@ def test_transform_metrics(golden):
         got = metrics_ref.transform_metrics(*c["args"])
         for k, v in c["result"].items():
             assert _close(got[k], v), (c, k)
+
+
+# ------------------------------------------------------------------ SURVEY §8f next rows
+def test_divergence_noise_metrics_and_sample_average(golden, models):
+    arrays, meta = golden
+    for c, d in zip(meta["manager_cases"], meta["divergence_cases"]):
+        tt = [(torch.from_numpy(x), t) for x, t in zip(arrays[c["key"] + "_teacher"], c["teacher_t"])]
+        st = [(torch.from_numpy(x), t) for x, t in zip(arrays[c["key"] + "_student"], c["student_t"])]
+        got = metrics_ref.trajectory_divergence(tt, st)
+        for k, v in d["result"].items():
+            assert _close(got[k], v, 1e-12), (c["key"], k)
+    got = metrics_ref.noise_metrics(torch.from_numpy(arrays["noise_teacher"]), torch.from_numpy(arrays["noise_student"]))
+    for k, v in meta["noise_metric_case"].items():
+        assert _close(got[k], v, 1e-12), k
+    c = meta["average_case"]
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = 16, c["T"]
+    with torch.no_grad():
+        ta, sa = sampler_ref.average_sample_trajectories(eps_fn(models(c["teacher_sf"])), eps_fn(models(c["student_sf"])), cfg,
+                                                         c["guidance_scales"], c["num_samples"], c["base_seed"])
+    for gs in c["guidance_scales"]:
+        assert np.array_equal(torch.stack(ta[gs]).numpy(), arrays[f"avg_teacher_{gs}"])
+        assert np.array_equal(torch.stack(sa[gs]).numpy(), arrays[f"avg_student_{gs}"])
