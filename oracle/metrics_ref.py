@@ -194,3 +194,16 @@ def noise_metrics(teacher_noise, student_noise):
     tf = torch.nn.functional.normalize(teacher_noise.view(teacher_noise.size(0), -1), p=2, dim=1)
     sf = torch.nn.functional.normalize(student_noise.view(student_noise.size(0), -1), p=2, dim=1)
     return {"mse": mse, "mae": mae, "cosine_similarity": torch.mean(torch.sum(tf * sf, dim=1)).item()}
+
+
+def calculate_fid(features_1, features_2):
+    """analysis/metrics/fid_score.py:61-93."""
+    from scipy import linalg
+    if len(features_1) < 2 or len(features_2) < 2:
+        return 999.0
+    mu1, s1 = features_1.mean(axis=0), np.cov(features_1, rowvar=False)
+    mu2, s2 = features_2.mean(axis=0), np.cov(features_2, rowvar=False)
+    covmean = linalg.sqrtm(s1.dot(s2))
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    return np.sum((mu1 - mu2) ** 2.0) + np.trace(s1 + s2 - 2.0 * covmean)

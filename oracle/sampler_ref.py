@@ -207,3 +207,31 @@ def average_sample_trajectories(teacher_fn, student_fn, cfg, guidance_scales, nu
         out.append({gs: [torch.mean(torch.stack([tr[t] for tr in per[k][gs]]), dim=0) for t in range(len(per[k][gs][0]))]
                     for gs in guidance_scales})
     return out[0], out[1]
+
+
+def fid_p_sample_loop(eps_fn, x, cfg):
+    """analysis/metrics/fid_score.py:261-318: DDPM posterior loop of the FID sample generator."""
+    T = cfg.timesteps
+    for t in range(T - 1, -1, -1):
+        eps = eps_fn(x, torch.tensor([t]), None)
+        beta_t = cfg.beta_start + (cfg.beta_end - cfg.beta_start) * t / T
+        alpha_t = 1.0 - beta_t
+        alpha_bar_t = 1.0
+        for i in range(t + 1):
+            alpha_bar_t *= 1.0 - (cfg.beta_start + (cfg.beta_end - cfg.beta_start) * i / T)
+        beta_t, alpha_t, alpha_bar_t = torch.as_tensor(beta_t), torch.as_tensor(alpha_t), torch.as_tensor(alpha_bar_t)
+        if t > 0:
+            noise = torch.randn_like(x)
+            x = (x - (1 - alpha_t) / torch.sqrt(1 - alpha_bar_t) * eps) / torch.sqrt(alpha_t)
+            x = x + torch.sqrt(beta_t) * noise
+        else:
+            x = (x - (1 - alpha_t) / torch.sqrt(1 - alpha_bar_t) * eps) / torch.sqrt(alpha_t)
+    return x
+
+
+def fid_generate_samples(eps_fn, cfg, num_samples):
+    """analysis/metrics/fid_score.py:199-259 without fixed samples."""
+    out = []
+    for _ in range(num_samples):
+        out.append(fid_p_sample_loop(eps_fn, torch.randn(1, cfg.channels, cfg.image_size, cfg.image_size), cfg))
+    return torch.cat(out, dim=0)

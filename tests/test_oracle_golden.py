@@ -196,3 +196,22 @@ def test_divergence_noise_metrics_and_sample_average(golden, models):
     for gs in c["guidance_scales"]:
         assert np.array_equal(torch.stack(ta[gs]).numpy(), arrays[f"avg_teacher_{gs}"])
         assert np.array_equal(torch.stack(sa[gs]).numpy(), arrays[f"avg_student_{gs}"])
+
+
+def test_fid_sampler_and_formula(golden, models):
+    arrays, meta = golden
+    c = meta["fid_case"]
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = 16, c["T"]
+    fn_samples, fn_loop = eps_fn(models(c["sf_samples"])), eps_fn(models(c["sf_loop"]))   # (model construction re-seeds)
+    x = seeded_noise(c["x_seed"], (2, 3, 16, 16))
+    torch.manual_seed(c["seed_samples"])
+    with torch.no_grad():
+        got = sampler_ref.fid_generate_samples(fn_samples, cfg, 3)
+    assert np.array_equal(got.numpy(), arrays["fid_samples"])
+    torch.manual_seed(c["seed_loop"])
+    with torch.no_grad():
+        got = sampler_ref.fid_p_sample_loop(fn_loop, x, cfg)
+    assert np.array_equal(got.numpy(), arrays["fid_loop"])
+    assert _close(metrics_ref.calculate_fid(arrays["fid_feat1"], arrays["fid_feat2"]), c["fid"], 1e-12)
+    assert metrics_ref.calculate_fid(arrays["fid_feat1"][:1], arrays["fid_feat2"]) == c["fid_too_few"] == 999.0
