@@ -40,7 +40,9 @@ __device__ inline void split8(const f32x4 lo, const f32x4 hi, bf16x8 &p1, bf16x8
   }
 }
 
-template <int BM, int BN>
+// ABL != 0 builds are timing experiments (tools/ablate.py) and produce wrong results by design:
+// 1 no barrier, 2 no LDS fragment reads after the first chunk, 3 no MFMA, 4 no global loads, 5 no split VALU
+template <int BM, int BN, int ABL = 0>
 __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvParams p) {
   constexpr int WN = 2;
   constexpr int MI = BM / 64, NI = BN / 64;
@@ -99,7 +101,11 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
     const bool more = it + 1 < n_iter;
     f32x4 ra0 = {0.f, 0.f, 0.f, 0.f}, ra1 = ra0;
     u32x4 rb[3];
-    if (more && it + 1 >= n_main) {
+    if (ABL == 4) {
+      ra0 = f32x4{1.f, 2.f, 3.f, 4.f}; ra1 = ra0;
+      rb[0] = rb[1] = rb[2] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      if (more && ++cc == CC) { cc = 0; ++tap; }
+    } else if (more && it + 1 >= n_main) {
       const int c2 = it + 1 - n_main;
       if (a_ok) {
         const float *src = p.in2 + a_off2 + c2 * 16;
@@ -131,19 +137,26 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
       if (it == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
       const __bf16 *A = lds + (it & 1) * STAGE, *B = A + 3 * PLANE_A;
       bf16x8 fb[NI][3];
+      u32x4 fake = {(unsigned)lane * 0x01010101u, 0x3f803f80u, (unsigned)it, 0x3c003c00u};   // ABL == 2 only
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fb[ni][pl] = *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
+        for (int pl = 0; pl < 3; ++pl)
+          fb[ni][pl] = ABL == 2 ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         bf16x8 fa[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fa[pl] = *reinterpret_cast<const bf16x8 *>(A + pl * PLANE_A + a_frag[mi]);
+        for (int pl = 0; pl < 3; ++pl)
+          fa[pl] = ABL == 2 ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(A + pl * PLANE_A + a_frag[mi]);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           // smallest terms first so their sum is formed before it meets the large partial sums
           f32x16 c = acc[mi][ni];
+          if (ABL == 3) {              // keep the fragments live, skip the matrix work
+            asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fb[ni][0]), "v"(fb[ni][1]), "v"(fb[ni][2]));
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ni][0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][1], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][2], c, 0, 0, 0);
@@ -158,6 +171,9 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
       __bf16 *A = lds + ((it + 1) & 1) * STAGE, *B = A + 3 * PLANE_A;
       if (a_thread) {
         bf16x8 p1, p2, p3;
+        if (ABL == 5) {                // no split VALU: park raw bits
+          p1 = __builtin_bit_cast(bf16x8, ra0); p2 = __builtin_bit_cast(bf16x8, ra1); p3 = p1;
+        } else
         split8(ra0, ra1, p1, p2, p3);
         *reinterpret_cast<bf16x8 *>(A + a_lds) = p1;
         *reinterpret_cast<bf16x8 *>(A + PLANE_A + a_lds) = p2;
@@ -168,13 +184,25 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(B + pl * PLANE_B + tid * 8) = rb[pl];
       }
     }
-    __syncthreads();
+    if (ABL != 1) __syncthreads();
   }
   conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
 }
 
 int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s) {
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
+  if (p.ablate && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
+    switch (p.ablate) {
+      case 1: conv_gemm_bf16x6_kernel<128, 128, 1><<<grid, 256, 0, s>>>(p); break;
+      case 2: conv_gemm_bf16x6_kernel<128, 128, 2><<<grid, 256, 0, s>>>(p); break;
+      case 3: conv_gemm_bf16x6_kernel<128, 128, 3><<<grid, 256, 0, s>>>(p); break;
+      case 4: conv_gemm_bf16x6_kernel<128, 128, 4><<<grid, 256, 0, s>>>(p); break;
+      case 5: conv_gemm_bf16x6_kernel<128, 128, 5><<<grid, 256, 0, s>>>(p); break;
+      default: return DT_E_ARG;
+    }
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
   if (bm == 128 && bn == 128) conv_gemm_bf16x6_kernel<128, 128><<<grid, 256, 0, s>>>(p);
   else if (bm == 128) conv_gemm_bf16x6_kernel<128, 64><<<grid, 256, 0, s>>>(p);
   else if (bn == 128) conv_gemm_bf16x6_kernel<64, 128><<<grid, 256, 0, s>>>(p);

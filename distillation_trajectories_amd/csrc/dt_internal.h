@@ -84,6 +84,7 @@ struct ConvParams {
   // inputs of the LDS-DMA kernel (prec == 2) and, when out_pl is set, an extra output of the epilogue
   const void *in_pl, *in2_pl, *zero;
   void *out_pl;
+  int ablate;          // timing experiments only (wrong results): 1 no barrier, 2 no LDS reads, 3 no MFMA, 4 no staging
 };
 
 int launch_conv(const ConvParams &p, hipStream_t s);

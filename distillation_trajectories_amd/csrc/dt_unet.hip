@@ -7,6 +7,7 @@
 //   up+cat(enc4) -> dec3 @H/8 -> up+cat(enc3) -> dec2 @H/4 -> up+cat(enc2) -> dec1 @H/2 -> up + 1x1 head @H
 // Each residual block is up to three implicit-GEMM launches (1x1 skip, conv1, conv2) whose epilogues
 // carry BN/ReLU/time-bias/residual, so a forward is 8 blocks * (2..3) + 4 pools + 3 upcats + 2 = ~32 launches.
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -539,6 +540,7 @@ int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block
   ConvParams p;
   if (!conv_slot(h, block, slot, in, ws, pl, batch_total, h->slab, batch_total, &c, p)) { *ms = 0.f; *flops = 0.0; return DT_OK; }
   *flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));
+  if (const char *ab = getenv("DT_ABLATE")) p.ablate = atoi(ab);   // timing experiments only
   hipEvent_t e0, e1;
   DT_HIP_TRY(hipEventCreate(&e0));
   DT_HIP_TRY(hipEventCreate(&e1));
