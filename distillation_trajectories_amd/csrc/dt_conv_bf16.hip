@@ -42,10 +42,12 @@ __device__ inline void split8(const f32x4 lo, const f32x4 hi, bf16x8 &p1, bf16x8
 
 // ABL != 0 builds are timing experiments (tools/ablate.py) and produce wrong results by design:
 // 1 no barrier, 2 no LDS fragment reads after the first chunk, 3 no MFMA, 4 no global loads, 5 no split VALU
-template <int BM, int BN, int ABL = 0>
-__global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvParams p) {
-  constexpr int WN = 2;
-  constexpr int MI = BM / 64, NI = BN / 64;
+// Wave layout: WM x WN waves (64*WM*WN threads) tile the BM x BN block; each wave owns (BM/WM) x (BN/WN).
+// Only 2x2 waves of <= 64x64 are instantiated: 256-row tiles (2x4 waves of 128x64, 4x2 of 64x64, 2x2 of 128x64)
+// were measured at 81 / 145 / 103 TF/s against 179 for 128x128 and are not built.
+template <int BM, int BN, int ABL = 0, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, BM * BN > 128 * 128 ? 2 : 3) void conv_gemm_bf16x6_kernel(const ConvParams p) {
+  constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
   constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;            // bf16 elements per plane per stage
   constexpr int STAGE = 3 * (PLANE_A + PLANE_B);                  // bf16 elements per stage
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
@@ -57,19 +59,25 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
   const int HW = p.H * p.W;
   const int CC = p.cin_p >> 4;
 
-  // ---- A staging: thread -> (row, k-half): 8 consecutive k = 32 contiguous bytes of one pixel
-  const bool a_thread = tid < BM * 2;
-  const int a_rowi = tid >> 1, a_hh = tid & 1;
-  const int a_m = m0 + a_rowi;
-  const bool a_ok = a_thread && a_m < p.M;
-  const int a_mm = a_ok ? a_m : 0;
-  const int a_b = a_mm / HW, a_rem = a_mm - a_b * HW;
-  const int a_y = a_rem / p.W, a_x = a_rem - a_y * p.W;
-  const int a_off = a_mm * p.cin_p + a_hh * 8;
-  const int a_off2 = a_mm * p.cin2_p + a_hh * 8;                    // fused skip walk
-  const int a_lds = a_rowi * 16 + ((a_hh ^ ((a_rowi >> 3) & 1)) << 3);   // element offset inside a plane
+  // ---- A staging: item -> (row, k-half): 8 consecutive k = 32 contiguous bytes of one pixel; AP items per thread
+  constexpr int NT = 64 * WM * WN;
+  constexpr int AP = (BM * 2 + NT - 1) / NT, BP = (BN * 2 + NT - 1) / NT;
+  bool a_ok[AP];
+  int a_y[AP], a_x[AP], a_off[AP], a_off2[AP], a_lds[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int item = tid + i * NT;
+    const int rowi = item >> 1, hh = item & 1;
+    const int m = m0 + rowi;
+    a_ok[i] = item < BM * 2 && m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int b = mm / HW, rem = mm - b * HW;
+    a_y[i] = rem / p.W; a_x[i] = rem - a_y[i] * p.W;
+    a_off[i] = mm * p.cin_p + hh * 8;
+    a_off2[i] = mm * p.cin2_p + hh * 8;                               // fused skip walk
+    a_lds[i] = rowi * 16 + ((hh ^ ((rowi >> 3) & 1)) << 3);          // element offset inside a plane
+  }
   // ---- B staging: the three plane tiles are contiguous [BN][16] bf16 runs in the packed weights
-  const bool b_thread = tid < BN * 2;
   const __bf16 *wbase = reinterpret_cast<const __bf16 *>(p.w) + (size_t)n0 * 16 + tid * 8;
   const size_t w_plane = (size_t)p.n_p * 16;                       // elements between planes of one chunk
 
@@ -99,38 +107,49 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
   int tap = p.tap_lo + blockIdx.z * taps_per, cc = 0;
   for (int it = -1; it < n_iter; ++it) {
     const bool more = it + 1 < n_iter;
-    f32x4 ra0 = {0.f, 0.f, 0.f, 0.f}, ra1 = ra0;
-    u32x4 rb[3];
+    f32x4 ra0[AP], ra1[AP];
+    u32x4 rb[BP][3];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) { ra0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ra1[i] = ra0[i]; }
     if (ABL == 4) {
-      ra0 = f32x4{1.f, 2.f, 3.f, 4.f}; ra1 = ra0;
-      rb[0] = rb[1] = rb[2] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      ra0[0] = f32x4{1.f, 2.f, 3.f, 4.f}; ra1[0] = ra0[0];
+      rb[0][0] = rb[0][1] = rb[0][2] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
       if (more && ++cc == CC) { cc = 0; ++tap; }
     } else if (more && it + 1 >= n_main) {
       const int c2 = it + 1 - n_main;
-      if (a_ok) {
-        const float *src = p.in2 + a_off2 + c2 * 16;
-        ra0 = *reinterpret_cast<const f32x4 *>(src);
-        ra1 = *reinterpret_cast<const f32x4 *>(src + 4);
-      }
-      if (b_thread) {
-        const __bf16 *wt = reinterpret_cast<const __bf16 *>(p.w2) + (size_t)n0 * 16 + tid * 8 + (size_t)c2 * 3 * w_plane;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rb[pl] = *reinterpret_cast<const u32x4 *>(wt + pl * w_plane);
-      }
+      for (int i = 0; i < AP; ++i)
+        if (a_ok[i]) {
+          const float *src = p.in2 + a_off2[i] + c2 * 16;
+          ra0[i] = *reinterpret_cast<const f32x4 *>(src);
+          ra1[i] = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
+      const __bf16 *wt = reinterpret_cast<const __bf16 *>(p.w2) + (size_t)n0 * 16 + tid * 8 + (size_t)c2 * 3 * w_plane;
+#pragma unroll
+      for (int i = 0; i < BP; ++i)
+        if (tid + i * NT < BN * 2) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) rb[i][pl] = *reinterpret_cast<const u32x4 *>(wt + i * NT * 8 + pl * w_plane);
+        }
     } else if (more) {
       int dy = 0, dx = 0;
       if (p.ksize == 3) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-      const int yy = a_y + dy, xx = a_x + dx;
-      if (a_ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
-        const float *src = p.in + a_off + (dy * p.W + dx) * p.cin_p + cc * 16;
-        ra0 = *reinterpret_cast<const f32x4 *>(src);
-        ra1 = *reinterpret_cast<const f32x4 *>(src + 4);
-      }
-      if (b_thread) {
-        const __bf16 *wt = wbase + (size_t)(tap * CC + cc) * 3 * w_plane;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rb[pl] = *reinterpret_cast<const u32x4 *>(wt + pl * w_plane);
+      for (int i = 0; i < AP; ++i) {
+        const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+        if (a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+          const float *src = p.in + a_off[i] + (dy * p.W + dx) * p.cin_p + cc * 16;
+          ra0[i] = *reinterpret_cast<const f32x4 *>(src);
+          ra1[i] = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
       }
+      const __bf16 *wt = wbase + (size_t)(tap * CC + cc) * 3 * w_plane;
+#pragma unroll
+      for (int i = 0; i < BP; ++i)
+        if (tid + i * NT < BN * 2) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) rb[i][pl] = *reinterpret_cast<const u32x4 *>(wt + i * NT * 8 + pl * w_plane);
+        }
       if (++cc == CC) { cc = 0; ++tap; }
     }
     if (it >= 0) {
@@ -169,20 +188,24 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bf16x6_kernel(const ConvPara
     }
     if (more) {
       __bf16 *A = lds + ((it + 1) & 1) * STAGE, *B = A + 3 * PLANE_A;
-      if (a_thread) {
-        bf16x8 p1, p2, p3;
-        if (ABL == 5) {                // no split VALU: park raw bits
-          p1 = __builtin_bit_cast(bf16x8, ra0); p2 = __builtin_bit_cast(bf16x8, ra1); p3 = p1;
-        } else
-        split8(ra0, ra1, p1, p2, p3);
-        *reinterpret_cast<bf16x8 *>(A + a_lds) = p1;
-        *reinterpret_cast<bf16x8 *>(A + PLANE_A + a_lds) = p2;
-        *reinterpret_cast<bf16x8 *>(A + 2 * PLANE_A + a_lds) = p3;
-      }
-      if (b_thread) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(B + pl * PLANE_B + tid * 8) = rb[pl];
-      }
+      for (int i = 0; i < AP; ++i)
+        if (tid + i * NT < BM * 2) {
+          bf16x8 p1, p2, p3;
+          if (ABL == 5) {                // no split VALU: park raw bits
+            p1 = __builtin_bit_cast(bf16x8, ra0[i]); p2 = __builtin_bit_cast(bf16x8, ra1[i]); p3 = p1;
+          } else
+          split8(ra0[i], ra1[i], p1, p2, p3);
+          *reinterpret_cast<bf16x8 *>(A + a_lds[i]) = p1;
+          *reinterpret_cast<bf16x8 *>(A + PLANE_A + a_lds[i]) = p2;
+          *reinterpret_cast<bf16x8 *>(A + 2 * PLANE_A + a_lds[i]) = p3;
+        }
+#pragma unroll
+      for (int i = 0; i < BP; ++i)
+        if (tid + i * NT < BN * 2) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(B + pl * PLANE_B + (tid + i * NT) * 8) = rb[i][pl];
+        }
     }
     if (ABL != 1) __syncthreads();
   }

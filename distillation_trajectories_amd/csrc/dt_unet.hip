@@ -560,7 +560,7 @@ int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block
 int dt_unet_set_precision(dt_unet *h, int precision) {
   if (!h) return DT_E_NULL;
   if (precision < DT_PREC_FP32 || precision > DT_PREC_AUTO_PLANES) return DT_E_ARG;
-  if (precision != h->precision) h->tuned.clear();
+  h->tuned.clear();                               // choices are per arithmetic mode: back to the heuristic plan
   h->precision = precision;
   h->planes = precision == DT_PREC_AUTO_PLANES;   // changes the workspace size: re-query dt_unet_workspace_bytes
   return DT_OK;
@@ -586,6 +586,38 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
     conv_slot(h, block, 2, &dummy, &dummy, pl, batch_total, &dummy, 1, t ? &t->c[block][2] : nullptr, c2);
     if (c2.in2) *bm = *bn = *splits = 0;
   }
+  return DT_OK;
+}
+
+int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn, int splits,
+                            int prec, int fuse) {
+  if (!h) return DT_E_NULL;
+  if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H < 16 || W < 16 || H % 16 || W % 16 || batch_total < 1)
+    return DT_E_ARG;
+  if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return DT_E_ARG;
+  if ((splits != 1 && splits != 3 && splits != 9) || prec < 0 || prec > 2 || (fuse && (slot != 2 || splits != 1)))
+    return DT_E_ARG;
+  if (prec == 2 && !h->planes) return DT_E_ARG;
+  if (h->blk[block].n_p % bn) return DT_E_ARG;
+  const Plan pl = make_plan(h, batch_total, H, W);
+  TunedShape *t = nullptr;
+  for (TunedShape &old : h->tuned)
+    if (old.Bt == batch_total && old.H == H && old.W == W) t = &old;
+  if (!t) {   // start from what an untuned forward would launch
+    TunedShape fresh{};
+    fresh.Bt = batch_total; fresh.H = H; fresh.W = W;
+    float dummy = 0.f;
+    for (int j = 0; j < kBlocks; ++j)
+      for (int sl = 0; sl < 3; ++sl) {
+        ConvParams p;
+        if (!conv_slot(h, j, sl, &dummy, &dummy, pl, batch_total, &dummy, 1, nullptr, p)) continue;
+        if (!p.bm || !p.bn) { const ConvChoice c = heuristic_choice(p.M, p.n_p, 1); p.bm = c.bm; p.bn = c.bn; }
+        fresh.c[j][sl] = ConvChoice{p.bm, p.bn, p.splits, p.prec, p.in2 ? 1 : 0};
+      }
+    h->tuned.push_back(fresh);
+    t = &h->tuned.back();
+  }
+  t->c[block][slot] = ConvChoice{bm, bn, splits, prec, fuse};
   return DT_OK;
 }
 

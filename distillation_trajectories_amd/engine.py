@@ -125,6 +125,12 @@ class UNetHandle:
                   "dt_unet_autotune")
         self._tuned.add(key)
 
+    def set_conv_choice(self, batch_total, H, W, block, slot, bm, bn, splits=1, prec=1, fuse=0):
+        """Pin one convolution's launch choice for this forward shape (dt_unet_set_conv_choice)."""
+        check(self.lib.dt_unet_set_conv_choice(self.h, batch_total, H, W, block, slot, bm, bn, splits, prec, fuse),
+              "dt_unet_set_conv_choice")
+        self._tuned.add((batch_total, H, W))
+
     def conv_choices(self, batch_total, H, W):
         """[(block, slot, bm, bn, splits, tuned)] for reporting."""
         out = []

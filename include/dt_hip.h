@@ -118,6 +118,12 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace_
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
                         int *splits, int *prec, int *tuned);
 
+/* tuning / test hook: pin the launch choice of one convolution of a forward shape (the other slots keep
+ * their current choice).  bm x bn in {64,128}^2;
+ * splits in {1,3,9} (ignored where the layer cannot be tap-split); fuse only for slot 2. */
+int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn,
+                            int splits, int prec, int fuse);
+
 /* tuning aid: time ONE convolution launch (block, slot) of a forward shape under an explicit choice
  * (prec: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 via LDS-DMA); averages `reps` launches with HIP events */
 int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn,

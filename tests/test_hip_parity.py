@@ -133,6 +133,35 @@ def test_unet_forward_large_batch_properties(gpu_models):
     h.set_precision(_hip.PREC_AUTO)
 
 
+def test_conv_tile_variants_match_oracle(gpu_models):
+    """Every launch shape of the conv kernels (tile, wave layout, tap split, arithmetic, fused skip), pinned one
+    layer at a time through dt_unet_set_conv_choice, against the oracle forward."""
+    m = gpu_models(1.0)
+    h = engine.UNetHandle.for_module(m)
+    B = 41                                           # 41 images: ragged against the 128-row tile below 4x4
+    x = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(5)).to(DEV)
+    tb = h.time_bias([9, 9], [_hip.COND_NONE, _hip.COND_ONE])
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = unet_ref.unet_forward(sd, x[:3].cpu(), torch.full((3,), 9), torch.ones(3, 1)).numpy()
+    tried = 0
+    for block in range(8):
+        for slot in (1, 2):
+            for prec, bm, bn, sp, fuse in [(0, 128, 128, 1, 0), (0, 64, 64, 3, 0), (1, 128, 128, 1, 0), (1, 64, 128, 9, 0),
+                                           (1, 128, 64, 1, 1), (1, 64, 64, 1, 0), (0, 128, 64, 1, 1), (0, 64, 128, 9, 0),
+                                           (1, 128, 128, 3, 0)]:
+                h.set_precision(_hip.PREC_AUTO)       # back to the heuristic plan
+                try:
+                    h.set_conv_choice(2 * B, 16, 16, block, slot, bm, bn, sp, prec, fuse if slot == 2 else 0)
+                except _hip.HipLibraryError:
+                    continue                           # tile wider than the layer's padded channel count
+                got = h.forward(x, tb, 2, B, tune=False)
+                assert_close(got[B:B + 3].cpu().numpy(), want, what=f"block {block} slot {slot} {prec}/{bm}x{bn}/s{sp}/f{fuse}")
+                tried += 1
+    h.set_precision(_hip.PREC_AUTO)
+    assert tried >= 100
+
+
 def test_time_bias_rows(gpu_models):
     m = gpu_models(0.2)
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
