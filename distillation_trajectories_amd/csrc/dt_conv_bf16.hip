@@ -21,25 +21,6 @@
 
 namespace dt {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ inline float bf16_to_f32(__bf16 v) { return (float)v; }
-
-// exact three-way split of 8 consecutive fp32 values into bf16 planes (packed 8 x bf16 = 16 B each)
-__device__ inline void split8(const f32x4 lo, const f32x4 hi, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float a = i < 4 ? lo[i] : hi[i - 4];
-    const __bf16 a1 = (__bf16)a;
-    const float r1 = a - (float)a1;
-    const __bf16 a2 = (__bf16)r1;
-    const float r2 = r1 - (float)a2;
-    p1[i] = a1; p2[i] = a2; p3[i] = (__bf16)r2;
-  }
-}
-
 // ABL != 0 builds are timing experiments (tools/ablate.py) and produce wrong results by design:
 // 1 no barrier, 2 no LDS fragment reads after the first chunk, 3 no MFMA, 4 no global loads, 5 no split VALU
 // Wave layout: WM x WN waves (64*WM*WN threads) tile the BM x BN block; each wave owns (BM/WM) x (BN/WN).

@@ -18,6 +18,25 @@ __device__ inline void split3(float v, __bf16 &a1, __bf16 &a2, __bf16 &a3) {
   a3 = (__bf16)(r1 - (float)a2);
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float bf16_to_f32(__bf16 v) { return (float)v; }
+
+// exact three-way split of 8 consecutive fp32 values into bf16 planes (packed 8 x bf16 = 16 B each)
+__device__ inline void split8(const f32x4 lo, const f32x4 hi, bf16x8 &p1, bf16x8 &p2, bf16x8 &p3) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a = i < 4 ? lo[i] : hi[i - 4];
+    const __bf16 a1 = (__bf16)a;
+    const float r1 = a - (float)a1;
+    const __bf16 a2 = (__bf16)r1;
+    const float r2 = r1 - (float)a2;
+    p1[i] = a1; p2[i] = a2; p3[i] = (__bf16)r2;
+  }
+}
+
 // element index of (row m, channel c, plane 0) in a planes tensor with cq = C/16 chunks per row
 __device__ inline size_t plane_index(size_t m, int c, int cq) { return ((m * cq + (c >> 4)) * 3) * 16 + (c & 15); }
 

@@ -1,0 +1,236 @@
+// 3x3 convolution on the split-bf16 arithmetic of dt_conv_bf16.hip with the activation tile staged ONCE per
+// 16-channel chunk and reused by all nine taps ("strip" kernel).
+//
+// The plain implicit-GEMM kernel re-stages its BM x 16 activation tile for every (tap, chunk): nine global
+// loads, nine 3-way bf16 splits and nine LDS writes of (nearly) the same pixels.  Here a workgroup keeps the
+// tile's rows PLUS a halo of W+1 pixels on either side in LDS as three bf16 planes:
+//      strip row s  <->  pixel m0 - (W+1) + s,      s in [0, BM + 2(W+1))
+// and tap (dy, dx) of output row r reads strip row r + (W+1) + dy*W + dx -- the same LDS image at a shifted row.
+// Taps that fall outside the picture (zero padding, also across picture boundaries inside a tile) read a
+// dedicated all-zero strip row instead; validity is a 9-bit mask per fragment row, computed once.
+// Per chunk: one strip load/split/write, then nine steps that only stage the 3 x BN x 16 weight tile of their
+// tap (double buffered) and run 24 MFMAs per wave.  ds_read_b128 stays conflict-free at any shift because the
+// half-swap swizzle is a function of the strip row (rows 8 apart always differ in it).
+//
+// Split-K runs over channel chunks (grid.z slabs, summed in z order by splitk_epilogue_kernel); the block's
+// fused 1x1 skip walk follows as single-tap chunks over in2 / w2, as in the plain kernel.
+#include "dt_conv_epilogue.h"
+
+namespace dt {
+
+extern __shared__ __attribute__((aligned(16))) __bf16 strip_lds[];
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_strip_bf16x6_kernel(const ConvParams p) {
+  constexpr int WN = 2, NT = 256;
+  constexpr int MI = BM / 64, NI = BN / 64;
+  constexpr int PLANE_B = BN * 16, STAGE_B = 3 * PLANE_B;         // bf16 elements
+  constexpr int AP = 2;                                            // strip items (row, k-half) per thread
+  const int halo = p.W + 1;
+  const int R = BM + 2 * halo;                                     // strip rows; row R is all zeros
+  const int PLANE_A = (R + 1) * 16;
+  __bf16 *As = strip_lds;                                          // [3][R+1][16]
+  __bf16 *Bs = strip_lds + 3 * PLANE_A;                            // [2][3][BN][16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int HW = p.H * p.W;
+  const int CC = p.cin_p >> 4;
+
+  // ---- strip staging: item -> (strip row, k-half), 32 contiguous bytes of one pixel
+  bool s_in[AP], s_ok[AP], s_core[AP];
+  int s_off[AP], s_off2[AP], s_lds[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int item = tid + i * NT;
+    const int srow = item >> 1, hh = item & 1;
+    const int m = m0 - halo + srow;
+    s_in[i] = item < 2 * R;
+    s_ok[i] = s_in[i] && m >= 0 && m < p.M;
+    s_core[i] = s_ok[i] && srow >= halo && srow < halo + BM;       // rows the single-tap skip walk needs
+    const int mm = s_ok[i] ? m : 0;
+    s_off[i] = mm * p.cin_p + hh * 8;
+    s_off2[i] = mm * p.cin2_p + hh * 8;
+    s_lds[i] = srow * 16 + ((hh ^ ((srow >> 3) & 1)) << 3);
+  }
+  // ---- weight staging: the three plane tiles of one (tap, chunk) are contiguous [BN][16] bf16 runs
+  const bool b_thread = tid < BN * 2;
+  const __bf16 *wbase = reinterpret_cast<const __bf16 *>(p.w) + (size_t)n0 * 16 + tid * 8;
+  const __bf16 *wbase2 = reinterpret_cast<const __bf16 *>(p.w2) + (size_t)n0 * 16 + tid * 8;
+  const size_t w_plane = (size_t)p.n_p * 16;
+
+  // ---- fragment rows: strip row of the centre tap and the 9-bit tap-validity mask
+  int a_row[MI];
+  unsigned a_mask[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row_i = wm * (MI * 32) + mi * 32 + l31;
+    const int m = m0 + row_i;
+    a_row[mi] = row_i + halo;
+    unsigned mask = 0;
+    if (m < p.M) {
+      const int rem = m % HW;
+      const int y = rem / p.W, x = rem - y * p.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << t;
+      }
+    }
+    a_mask[mi] = mask;
+  }
+  int b_frag[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = wn * (NI * 32) + ni * 32 + l31;
+    b_frag[ni] = row * 16 + ((half ^ ((row >> 3) & 1)) << 3);
+  }
+  const int zero_e = R * 16 + (half << 3);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int n_main = CC / p.splits;                                // channel chunks of this z slice
+  const int cc0 = blockIdx.z * n_main;
+  const int n_chunks = n_main + (p.in2 ? (p.cin2_p >> 4) : 0);
+
+  f32x4 sa0[AP], sa1[AP];
+  u32x4 rb[3];
+  auto load_strip = [&](int ch) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      sa0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; sa1[i] = sa0[i];
+      if (ch < n_main) {
+        if (s_ok[i]) {
+          const float *src = p.in + s_off[i] + (cc0 + ch) * 16;
+          sa0[i] = *reinterpret_cast<const f32x4 *>(src);
+          sa1[i] = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
+      } else if (s_core[i]) {
+        const float *src = p.in2 + s_off2[i] + (ch - n_main) * 16;
+        sa0[i] = *reinterpret_cast<const f32x4 *>(src);
+        sa1[i] = *reinterpret_cast<const f32x4 *>(src + 4);
+      }
+    }
+  };
+  auto write_strip = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+      if (s_in[i]) {
+        bf16x8 p1, p2, p3;
+        split8(sa0[i], sa1[i], p1, p2, p3);
+        *reinterpret_cast<bf16x8 *>(As + s_lds[i]) = p1;
+        *reinterpret_cast<bf16x8 *>(As + PLANE_A + s_lds[i]) = p2;
+        *reinterpret_cast<bf16x8 *>(As + 2 * PLANE_A + s_lds[i]) = p3;
+      }
+  };
+  auto load_b = [&](int ch, int t) __attribute__((always_inline)) {
+    if (b_thread) {
+      const __bf16 *wt = ch < n_main ? wbase + (size_t)(t * CC + cc0 + ch) * 3 * w_plane
+                                     : wbase2 + (size_t)(ch - n_main) * 3 * w_plane;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) rb[pl] = *reinterpret_cast<const u32x4 *>(wt + pl * w_plane);
+    }
+  };
+  auto write_b = [&](int stage) __attribute__((always_inline)) {
+    if (b_thread) {
+      __bf16 *B = Bs + stage * STAGE_B;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(B + pl * PLANE_B + tid * 8) = rb[pl];
+    }
+  };
+
+  // ---- prologue: strip of chunk 0, weights of step 0, the zero row
+  load_strip(0);
+  load_b(0, 0);
+  if (tid < 6) *reinterpret_cast<u32x4 *>(As + (tid >> 1) * PLANE_A + R * 16 + (tid & 1) * 8) = u32x4{0u, 0u, 0u, 0u};
+  write_strip();
+  write_b(0);
+  __syncthreads();
+
+  int ch = 0, t = 0, step = 0;
+  while (true) {
+    const int ntaps = ch < n_main ? 9 : 1;
+    const bool last_tap = t == ntaps - 1;
+    const bool next_chunk = ch + 1 < n_chunks;
+    const bool more = !last_tap || next_chunk;
+    if (t == 0 && next_chunk) load_strip(ch + 1);                 // lands while this chunk's taps run
+    if (more) load_b(last_tap ? ch + 1 : ch, last_tap ? 0 : t + 1);
+
+    {
+      const int tt = ch < n_main ? t : 4;                          // the skip walk is a centre tap
+      const int shift = (tt / 3 - 1) * p.W + (tt % 3 - 1);
+      int a_e[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int srow = a_row[mi] + shift;
+        const int e = srow * 16 + ((half ^ ((srow >> 3) & 1)) << 3);
+        a_e[mi] = ((a_mask[mi] >> tt) & 1u) ? e : zero_e;
+      }
+      const __bf16 *B = Bs + (step & 1) * STAGE_B;
+      bf16x8 fb[NI][3];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fb[ni][pl] = *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        bf16x8 fa[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fa[pl] = *reinterpret_cast<const bf16x8 *>(As + pl * PLANE_A + a_e[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          // smallest terms first so their sum is formed before it meets the large partial sums
+          f32x16 c = acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][0], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+      }
+    }
+
+    if (more) write_b((step + 1) & 1);
+    if (last_tap && next_chunk) {
+      __syncthreads();                                             // every wave is done with this chunk's strip
+      write_strip();
+    }
+    __syncthreads();
+    ++step;
+    if (last_tap) {
+      if (ch + 1 == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
+      if (!next_chunk) break;
+      ++ch; t = 0;
+    } else {
+      ++t;
+    }
+  }
+  conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
+}
+
+int launch_conv_strip(const ConvParams &p, int bm, int bn, hipStream_t s) {
+  if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || (p.cin_p >> 4) % p.splits) return DT_E_ARG;
+  if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 strip items per thread cover BM + 2(W+1) <= 256 rows
+  dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
+  const int R = bm + 2 * (p.W + 1);
+  const size_t lds = ((size_t)3 * (R + 1) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
+  if (lds > 65536) return DT_E_SHAPE;
+  if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128><<<grid, 256, lds, s>>>(p);
+  else if (bm == 128) conv_strip_bf16x6_kernel<128, 64><<<grid, 256, lds, s>>>(p);
+  else if (bn == 128) conv_strip_bf16x6_kernel<64, 128><<<grid, 256, lds, s>>>(p);
+  else conv_strip_bf16x6_kernel<64, 64><<<grid, 256, lds, s>>>(p);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+}  // namespace dt

@@ -51,7 +51,9 @@ const char *kClassName[KC_COUNT] = {
     "conv_gemm_kernel<128,128>", "conv_gemm_kernel<128,64>", "conv_gemm_kernel<64,128>", "conv_gemm_kernel<64,64>",
     "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
     "conv_gemm_bf16x6_kernel<64,64>", "conv_gemm_bf16x6_dma_kernel<128,128>", "conv_gemm_bf16x6_dma_kernel<128,64>",
-    "conv_gemm_bf16x6_dma_kernel<64,128>", "conv_gemm_bf16x6_dma_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "conv_gemm_bf16x6_dma_kernel<64,128>", "conv_gemm_bf16x6_dma_kernel<64,64>",
+    "conv_strip_bf16x6_kernel<128,128>", "conv_strip_bf16x6_kernel<128,64>", "conv_strip_bf16x6_kernel<64,128>",
+    "conv_strip_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
@@ -223,7 +225,9 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
   if (!choice) c.prec = u->precision == DT_PREC_FP32 ? 0 : (p.in_pl ? 2 : 1);   // untuned default per mode
   if (c.prec == 2 && !p.in_pl) c.prec = 1;
+  if (c.prec == 3 && taps != 9) c.prec = 1;                         // the strip kernel is the full 3x3 walk only
   if (taps != 9 || p.M > kSplitMaxRows) c.splits = 1;
+  if (c.prec == 3 ? ((p.cin_p >> 4) % c.splits != 0) : (9 % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
   if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
   if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0) {
@@ -476,14 +480,18 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       float best_ms = 1e30f;
       const bool can_fuse = slot == 2 && j > 0 && h->blk[j].has_res;
       const BlockW &kw = h->blk[j];
-      for (int prec = 0; prec <= 2; ++prec) {
+      const bool full3x3 = p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && !p.x3;
+      for (int prec = 0; prec <= 3; ++prec) {
         if ((h->precision == DT_PREC_FP32 && prec >= 1) || (h->precision == DT_PREC_SPLIT_BF16 && prec == 0)) continue;
         if (prec == 2 && !p.in_pl) continue;
+        if (prec == 3 && !full3x3) continue;
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
-          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= 3)
+          // tap splits 1/3/9; the strip kernel splits the channel chunks instead: 1/2/4/8
+          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= (prec == 3 ? 2 : 3))
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
+            if (prec == 3 && (p.cin_p >> 4) % sp) continue;
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
             q.w = prec ? (slot == 0 ? kw.wrb : (slot == 1 ? kw.w1b : kw.w2b)) : (slot == 0 ? kw.wr : (slot == 1 ? kw.w1 : kw.w2));
@@ -595,8 +603,8 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
   if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H < 16 || W < 16 || H % 16 || W % 16 || batch_total < 1)
     return DT_E_ARG;
   if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return DT_E_ARG;
-  if ((splits != 1 && splits != 3 && splits != 9) || prec < 0 || prec > 2 || (fuse && (slot != 2 || splits != 1)))
-    return DT_E_ARG;
+  if (splits < 1 || splits > 9 || prec < 0 || prec > 3 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
+  if (prec != 3 && 9 % splits) return DT_E_ARG;
   if (prec == 2 && !h->planes) return DT_E_ARG;
   if (h->blk[block].n_p % bn) return DT_E_ARG;
   const Plan pl = make_plan(h, batch_total, H, W);

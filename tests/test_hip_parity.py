@@ -149,7 +149,8 @@ def test_conv_tile_variants_match_oracle(gpu_models):
         for slot in (1, 2):
             for prec, bm, bn, sp, fuse in [(0, 128, 128, 1, 0), (0, 64, 64, 3, 0), (1, 128, 128, 1, 0), (1, 64, 128, 9, 0),
                                            (1, 128, 64, 1, 1), (1, 64, 64, 1, 0), (0, 128, 64, 1, 1), (0, 64, 128, 9, 0),
-                                           (1, 128, 128, 3, 0)]:
+                                           (1, 128, 128, 3, 0), (3, 128, 128, 1, 0), (3, 128, 64, 2, 0), (3, 64, 128, 4, 0),
+                                           (3, 64, 64, 1, 1), (3, 128, 128, 1, 1)]:
                 h.set_precision(_hip.PREC_AUTO)       # back to the heuristic plan
                 try:
                     h.set_conv_choice(2 * B, 16, 16, block, slot, bm, bn, sp, prec, fuse if slot == 2 else 0)
@@ -159,7 +160,7 @@ def test_conv_tile_variants_match_oracle(gpu_models):
                 assert_close(got[B:B + 3].cpu().numpy(), want, what=f"block {block} slot {slot} {prec}/{bm}x{bn}/s{sp}/f{fuse}")
                 tried += 1
     h.set_precision(_hip.PREC_AUTO)
-    assert tried >= 100
+    assert tried >= 130
 
 
 def test_time_bias_rows(gpu_models):
