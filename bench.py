@@ -273,7 +273,7 @@ def main():
     if kernels:
         dom_name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
         total_ms = sum(k["ms"] for k in kernels.values())
-        conv = {n: k for n, k in kernels.items() if n.startswith("conv_gemm")}
+        conv = {n: k for n, k in kernels.items() if n.startswith(("conv_gemm", "conv_strip"))}
         conv_ms, conv_fl = sum(k["ms"] for k in conv.values()), sum(k["flops"] for k in conv.values())
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         split = "bf16x6" in dom_name

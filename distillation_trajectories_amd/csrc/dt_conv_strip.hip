@@ -12,6 +12,9 @@
 // tap (double buffered) and run 24 MFMAs per wave.  ds_read_b128 stays conflict-free at any shift because the
 // half-swap swizzle is a function of the strip row (rows 8 apart always differ in it).
 //
+// (Loading the weight fragments straight from global memory instead -- no weight LDS traffic, no barrier per
+// tap, double-buffered strip -- was measured 3-8 % slower: 181 vs 186, 149 vs 156, 171 vs 181 TF/s.)
+//
 // Split-K runs over channel chunks (grid.z slabs, summed in z order by splitk_epilogue_kernel); the block's
 // fused 1x1 skip walk follows as single-tap chunks over in2 / w2, as in the plain kernel.
 #include "dt_conv_epilogue.h"
@@ -21,7 +24,7 @@ namespace dt {
 extern __shared__ __attribute__((aligned(16))) __bf16 strip_lds[];
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_strip_bf16x6_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvParams p) {
   constexpr int WN = 2, NT = 256;
   constexpr int MI = BM / 64, NI = BN / 64;
   constexpr int PLANE_B = BN * 16, STAGE_B = 3 * PLANE_B;         // bf16 elements

@@ -225,7 +225,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
   if (!choice) c.prec = u->precision == DT_PREC_FP32 ? 0 : (p.in_pl ? 2 : 1);   // untuned default per mode
   if (c.prec == 2 && !p.in_pl) c.prec = 1;
-  if (c.prec == 3 && taps != 9) c.prec = 1;                         // the strip kernel is the full 3x3 walk only
+  if (c.prec == 3 && p.tap_hi - p.tap_lo != 9) c.prec = 1;          // the strip kernel is the full 3x3 walk only
   if (taps != 9 || p.M > kSplitMaxRows) c.splits = 1;
   if (c.prec == 3 ? ((p.cin_p >> 4) % c.splits != 0) : (9 % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
@@ -480,7 +480,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       float best_ms = 1e30f;
       const bool can_fuse = slot == 2 && j > 0 && h->blk[j].has_res;
       const BlockW &kw = h->blk[j];
-      const bool full3x3 = p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && !p.x3;
+      const bool full3x3 = p.ksize == 3 && p.tap_hi - p.tap_lo == 9;
       for (int prec = 0; prec <= 3; ++prec) {
         if ((h->precision == DT_PREC_FP32 && prec >= 1) || (h->precision == DT_PREC_SPLIT_BF16 && prec == 0)) continue;
         if (prec == 2 && !p.in_pl) continue;
