@@ -12,8 +12,9 @@
 // tap (double buffered) and run 24 MFMAs per wave.  ds_read_b128 stays conflict-free at any shift because the
 // half-swap swizzle is a function of the strip row (rows 8 apart always differ in it).
 //
-// (Loading the weight fragments straight from global memory instead -- no weight LDS traffic, no barrier per
-// tap, double-buffered strip -- was measured 3-8 % slower: 181 vs 186, 149 vs 156, 171 vs 181 TF/s.)
+// (Measured and not kept: weight fragments straight from global memory -- no weight LDS traffic, no barrier per
+// tap, double-buffered strip -- 3-8 % slower (181 vs 186, 149 vs 156, 171 vs 181 TF/s); the weight tile through
+// global_load_lds into a ring of three, prefetched two taps ahead with counted vmcnt -- 1-5 % slower.)
 //
 // Split-K runs over channel chunks (grid.z slabs, summed in z order by splitk_epilogue_kernel); the block's
 // fused 1x1 skip walk follows as single-tap chunks over in2 / w2, as in the plain kernel.
@@ -23,7 +24,9 @@ namespace dt {
 
 extern __shared__ __attribute__((aligned(16))) __bf16 strip_lds[];
 
-template <int BM, int BN>
+// ABL != 0: timing experiments (wrong results): 1 no per-tap barrier, 2 no weight staging, 3 no MFMA,
+// 4 no fragment reads after the first step, 5 no strip re-staging
+template <int BM, int BN, int ABL = 0>
 __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvParams p) {
   constexpr int WN = 2, NT = 256;
   constexpr int MI = BM / 64, NI = BN / 64;
@@ -164,8 +167,8 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
     const bool last_tap = t == ntaps - 1;
     const bool next_chunk = ch + 1 < n_chunks;
     const bool more = !last_tap || next_chunk;
-    if (t == 0 && next_chunk) load_strip(ch + 1);                 // lands while this chunk's taps run
-    if (more) load_b(last_tap ? ch + 1 : ch, last_tap ? 0 : t + 1);
+    if (t == 0 && next_chunk && ABL != 5) load_strip(ch + 1);     // lands while this chunk's taps run
+    if (more && ABL != 2) load_b(last_tap ? ch + 1 : ch, last_tap ? 0 : t + 1);
 
     {
       const int tt = ch < n_main ? t : 4;                          // the skip walk is a centre tap
@@ -179,19 +182,26 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
       }
       const __bf16 *B = Bs + (step & 1) * STAGE_B;
       bf16x8 fb[NI][3];
+      const u32x4 fake = {(unsigned)lane * 0x01010101u + (unsigned)a_e[0], 0x3f803f80u, (unsigned)step, 0x3c003c00u};   // ABL == 4 only
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fb[ni][pl] = *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
+        for (int pl = 0; pl < 3; ++pl)
+          fb[ni][pl] = (ABL == 4) ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         bf16x8 fa[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fa[pl] = *reinterpret_cast<const bf16x8 *>(As + pl * PLANE_A + a_e[mi]);
+        for (int pl = 0; pl < 3; ++pl)
+          fa[pl] = (ABL == 4) ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(As + pl * PLANE_A + a_e[mi]);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           // smallest terms first so their sum is formed before it meets the large partial sums
           f32x16 c = acc[mi][ni];
+          if (ABL == 3) {              // keep the fragments live, skip the matrix work
+            asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fb[ni][0]), "v"(fb[ni][1]), "v"(fb[ni][2]));
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ni][0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][1], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][2], c, 0, 0, 0);
@@ -203,12 +213,12 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
       }
     }
 
-    if (more) write_b((step + 1) & 1);
-    if (last_tap && next_chunk) {
+    if (more && ABL != 2) write_b((step + 1) & 1);
+    if (last_tap && next_chunk && ABL != 5) {
       __syncthreads();                                             // every wave is done with this chunk's strip
       write_strip();
     }
-    __syncthreads();
+    if (ABL != 1 || last_tap) __syncthreads();
     ++step;
     if (last_tap) {
       if (ch + 1 == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
@@ -228,6 +238,18 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, hipStream_t s) {
   const int R = bm + 2 * (p.W + 1);
   const size_t lds = ((size_t)3 * (R + 1) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
   if (lds > 65536) return DT_E_SHAPE;
+  if (p.ablate && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
+    switch (p.ablate) {
+      case 1: conv_strip_bf16x6_kernel<128, 128, 1><<<grid, 256, lds, s>>>(p); break;
+      case 2: conv_strip_bf16x6_kernel<128, 128, 2><<<grid, 256, lds, s>>>(p); break;
+      case 3: conv_strip_bf16x6_kernel<128, 128, 3><<<grid, 256, lds, s>>>(p); break;
+      case 4: conv_strip_bf16x6_kernel<128, 128, 4><<<grid, 256, lds, s>>>(p); break;
+      case 5: conv_strip_bf16x6_kernel<128, 128, 5><<<grid, 256, lds, s>>>(p); break;
+      default: return DT_E_ARG;
+    }
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
   if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128><<<grid, 256, lds, s>>>(p);
   else if (bm == 128) conv_strip_bf16x6_kernel<128, 64><<<grid, 256, lds, s>>>(p);
   else if (bn == 128) conv_strip_bf16x6_kernel<64, 128><<<grid, 256, lds, s>>>(p);

@@ -16,13 +16,16 @@ h.forward(x, tb, 2, 256, tune=False)
 ws = h.workspace(512, 16, 16)
 lib = _hip.load()
 layers = [(0, 2, "enc1.conv2"), (1, 2, "enc2.conv2"), (7, 1, "dec1.conv1"), (2, 1, "enc3.conv1")]
-for ab, name in ((0, "full"), (1, "no barrier"), (2, "no LDS fragment reads"), (3, "no MFMA"), (4, "no global loads"), (5, "no split VALU")):
+PREC = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # 1: plain split-bf16 kernel, 3: strip kernel
+NAMES = {1: ((0, "full"), (1, "no barrier"), (2, "no LDS fragment reads"), (3, "no MFMA"), (4, "no global loads"), (5, "no split VALU")),
+         3: ((0, "full"), (1, "no per-tap barrier"), (2, "no weight staging"), (3, "no MFMA"), (4, "no fragment reads"), (5, "no strip re-staging"))}
+for ab, name in NAMES[PREC]:
     os.environ["DT_ABLATE"] = str(ab)
     row = f"{name:28s}"
     for j, slot, lname in layers:
         ms, fl = ctypes.c_float(), ctypes.c_double()
-        sp = 3 if lname in ("dec1.conv1", "enc3.conv1") else 1
-        st = lib.dt_unet_time_conv(h.h, 512, 16, 16, j, slot, 128, 128, sp, 1, 0, 10, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(),
+        sp = (3 if PREC == 1 else 2) if lname in ("dec1.conv1", "enc3.conv1") else 1
+        st = lib.dt_unet_time_conv(h.h, 512, 16, 16, j, slot, 128, 128, sp, PREC, 0, 10, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(),
                                    ctypes.byref(ms), ctypes.byref(fl))
         row += f" {lname} {ms.value*1e3:7.1f}us" if st == 0 else f" {lname} ERR{st}"
     print(row, flush=True)
