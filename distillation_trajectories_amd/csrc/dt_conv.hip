@@ -72,10 +72,10 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
   // Software pipeline, one barrier per chunk: iteration `it` issues the global loads of chunk it+1
   // into registers, runs the MFMAs of chunk it from LDS stage it&1, then parks the registers in the
   // other stage.  it == -1 is the prologue (loads chunk 0, no compute).
-  const int taps_per = (p.tap_hi - p.tap_lo) / p.splits;
-  const int n_main = taps_per * CC;
+  // split-K: grid.z slices the (tap, channel chunk) walk into equal runs of whole chunks
+  const int n_main = (p.tap_hi - p.tap_lo) * CC / p.splits;
   const int n_iter = n_main + (p.in2 ? (p.cin2_p >> 4) : 0);   // main walk, then the fused 1x1 skip walk
-  int tap = p.tap_lo + blockIdx.z * taps_per, cc = 0;
+  int tap = p.tap_lo + (blockIdx.z * n_main) / CC, cc = (blockIdx.z * n_main) % CC;
   for (int it = -1; it < n_iter; ++it) {
     const bool more = it + 1 < n_iter;
     f32x4 ra[A_PER], rb[B_PER];
@@ -152,7 +152,7 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
   const bool tall_m = bm == 128, wide_n = bn == 128;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   if (p.splits < 1 || (p.splits > 1 && !p.slab)) return DT_E_ARG;
-  if (p.prec == 3 ? ((p.cin_p >> 4) % p.splits != 0) : ((p.tap_hi - p.tap_lo) % p.splits != 0)) return DT_E_ARG;
+  if (p.prec == 3 ? ((p.cin_p >> 4) % p.splits != 0) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % p.splits != 0)) return DT_E_ARG;
   // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
   if (p.in2 && (p.splits != 1 || !p.w2 || !p.bias2 || p.cin2_p % 16)) return DT_E_ARG;
   const double flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));

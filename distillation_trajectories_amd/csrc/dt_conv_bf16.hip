@@ -82,10 +82,10 @@ __global__ __launch_bounds__(64 * WM * WN, BM * BN > 128 * 128 ? 2 : 3) void con
     b_frag[ni] = row * 16 + ((half ^ ((row >> 3) & 1)) << 3);
   }
 
-  const int taps_per = (p.tap_hi - p.tap_lo) / p.splits;
-  const int n_main = taps_per * CC;
+  // split-K: grid.z slices the (tap, channel chunk) walk into equal runs of whole chunks
+  const int n_main = (p.tap_hi - p.tap_lo) * CC / p.splits;
   const int n_iter = n_main + (p.in2 ? (p.cin2_p >> 4) : 0);       // main walk, then the fused 1x1 skip walk
-  int tap = p.tap_lo + blockIdx.z * taps_per, cc = 0;
+  int tap = p.tap_lo + (blockIdx.z * n_main) / CC, cc = (blockIdx.z * n_main) % CC;
   for (int it = -1; it < n_iter; ++it) {
     const bool more = it + 1 < n_iter;
     f32x4 ra0[AP], ra1[AP];

@@ -80,10 +80,10 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_bf16x6_dma_kernel(const Conv
     b_frag[ni] = row * 16 + ((half ^ ((row >> 3) & 1)) << 3);
   }
 
-  const int taps_per = (p.tap_hi - p.tap_lo) / p.splits;
-  const int n_main = taps_per * CC;
+  // split-K: grid.z slices the (tap, channel chunk) walk into equal runs of whole chunks
+  const int n_main = (p.tap_hi - p.tap_lo) * CC / p.splits;
   const int n_iter = n_main + (p.in2_pl ? (p.cin2_p >> 4) : 0);    // main walk, then the fused 1x1 skip walk
-  int tap = p.tap_lo + blockIdx.z * taps_per, cc = 0, next = 0;
+  int tap = p.tap_lo + (blockIdx.z * n_main) / CC, cc = (blockIdx.z * n_main) % CC, next = 0;
 
   // issue the DMAs of chunk `next` into LDS stage `stage`
   auto issue = [&](int stage) __attribute__((always_inline)) {

@@ -157,8 +157,8 @@ Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
     }
     p.r[j] = (u->blk[j].has_res && j > 0) ? b.take(px * u->blk[j].cout_p) : 0;
     p.o[j] = b.take(px * u->blk[j].cout_p);
-    if (j > 0 && !(h == 1 && w == 1) && px <= (size_t)kSplitMaxRows) {
-      const size_t need = (size_t)9 * px * u->blk[j].cout_p;    // room for the deepest tap split
+    if (j > 0 && px <= (size_t)kSplitMaxRows) {
+      const size_t need = (size_t)9 * px * u->blk[j].cout_p;    // room for the deepest split
       if (need > slab) slab = need;
     }
   }
@@ -223,11 +223,18 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     }
   }
   ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
-  if (!choice) c.prec = u->precision == DT_PREC_FP32 ? 0 : (p.in_pl ? 2 : 1);   // untuned default per mode
+  if (!choice) {   // untuned default per mode; the strip kernel wherever the full 3x3 walk runs (uniformly >= the plain one)
+    c.prec = u->precision == DT_PREC_FP32 ? 0 : (p.in_pl ? 2 : 1);
+    if (c.prec == 1 && p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && p.W + 1 <= 64) {
+      c.prec = 3;
+      const int cc = p.cin_p >> 4;   // tap groups 3 / 9 become channel-chunk groups 4 / 8 where they divide
+      c.splits = c.splits == 9 ? (cc % 8 == 0 ? 8 : (cc % 4 == 0 ? 4 : 1)) : (c.splits == 3 ? (cc % 4 == 0 ? 4 : (cc % 2 == 0 ? 2 : 1)) : 1);
+    }
+  }
   if (c.prec == 2 && !p.in_pl) c.prec = 1;
   if (c.prec == 3 && p.tap_hi - p.tap_lo != 9) c.prec = 1;          // the strip kernel is the full 3x3 walk only
-  if (taps != 9 || p.M > kSplitMaxRows) c.splits = 1;
-  if (c.prec == 3 ? ((p.cin_p >> 4) % c.splits != 0) : (9 % c.splits != 0)) c.splits = 1;
+  if (p.x3 || j == 0 || p.M > kSplitMaxRows) c.splits = 1;          // (enc1: no slab; its conv2 keeps the fused x3 epilogue)
+  if (c.prec == 3 ? ((p.cin_p >> 4) % c.splits != 0) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
   if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
   if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0) {
@@ -475,7 +482,8 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
         const ConvChoice unfused{p.bm, p.bn, p.splits, p.prec, 0};
         conv_slot(h, j, slot, in, ws, pl, batch_total, tb, batch_total, &unfused, p);
       }
-      const bool can_split = p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && !p.x3 && p.M <= kSplitMaxRows;
+      const bool can_split = j > 0 && !p.x3 && p.M <= kSplitMaxRows;
+      const bool walk9 = p.tap_hi - p.tap_lo == 9;
       ConvChoice best{p.bm, p.bn, p.splits, p.prec, 0};
       float best_ms = 1e30f;
       const bool can_fuse = slot == 2 && j > 0 && h->blk[j].has_res;
@@ -488,10 +496,10 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
-          // tap splits 1/3/9; the strip kernel splits the channel chunks instead: 1/2/4/8
-          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= (prec == 3 ? 2 : 3))
+          // 3x3 walks split by taps 1/3/9; the strip kernel and single-tap layers by channel chunks 1/2/4/8
+          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= ((prec == 3 || !walk9) ? 2 : 3))
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
-            if (prec == 3 && (p.cin_p >> 4) % sp) continue;
+            if ((prec == 3 || !walk9) && (p.cin_p >> 4) % sp) continue;
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
             q.w = prec ? (slot == 0 ? kw.wrb : (slot == 1 ? kw.w1b : kw.w2b)) : (slot == 0 ? kw.wr : (slot == 1 ? kw.w1 : kw.w2));
@@ -604,7 +612,7 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
     return DT_E_ARG;
   if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return DT_E_ARG;
   if (splits < 1 || splits > 9 || prec < 0 || prec > 3 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
-  if (prec != 3 && 9 % splits) return DT_E_ARG;
+  if (splits == 5 || splits == 6 || splits == 7) return DT_E_ARG;
   if (prec == 2 && !h->planes) return DT_E_ARG;
   if (h->blk[block].n_p % bn) return DT_E_ARG;
   const Plan pl = make_plan(h, batch_total, H, W);

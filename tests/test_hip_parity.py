@@ -150,7 +150,7 @@ def test_conv_tile_variants_match_oracle(gpu_models):
             for prec, bm, bn, sp, fuse in [(0, 128, 128, 1, 0), (0, 64, 64, 3, 0), (1, 128, 128, 1, 0), (1, 64, 128, 9, 0),
                                            (1, 128, 64, 1, 1), (1, 64, 64, 1, 0), (0, 128, 64, 1, 1), (0, 64, 128, 9, 0),
                                            (1, 128, 128, 3, 0), (3, 128, 128, 1, 0), (3, 128, 64, 2, 0), (3, 64, 128, 4, 0),
-                                           (3, 64, 64, 1, 1), (3, 128, 128, 1, 1)]:
+                                           (3, 64, 64, 1, 1), (3, 128, 128, 1, 1), (1, 64, 64, 4, 0), (0, 64, 64, 2, 0), (1, 128, 64, 8, 0)]:
                 h.set_precision(_hip.PREC_AUTO)       # back to the heuristic plan
                 try:
                     h.set_conv_choice(2 * B, 16, 16, block, slot, bm, bn, sp, prec, fuse if slot == 2 else 0)
@@ -159,8 +159,24 @@ def test_conv_tile_variants_match_oracle(gpu_models):
                 got = h.forward(x, tb, 2, B, tune=False)
                 assert_close(got[B:B + 3].cpu().numpy(), want, what=f"block {block} slot {slot} {prec}/{bm}x{bn}/s{sp}/f{fuse}")
                 tried += 1
+    # the blocks' 1x1 skip convolutions as launches of their own (conv2 pinned unfused), with channel-chunk splits
+    skips = 0
+    for block in range(1, 8):
+        for prec, bm, bn, sp in [(1, 64, 64, 1), (1, 64, 64, 2), (1, 128, 64, 4), (0, 64, 64, 8), (0, 64, 128, 1)]:
+            h.set_precision(_hip.PREC_AUTO)
+            try:
+                h.set_conv_choice(2 * B, 16, 16, block, 2, 64, 64, 1, 1, 0)
+                h.set_conv_choice(2 * B, 16, 16, block, 0, bm, bn, sp, prec, 0)
+            except _hip.HipLibraryError:
+                continue
+            names = {(c[0], c[1]) for c in h.conv_choices(2 * B, 16, 16)}
+            if (engine.BLOCK_NAMES[block], "skip") not in names:
+                continue                               # identity skip: no launch
+            got = h.forward(x, tb, 2, B, tune=False)
+            assert_close(got[B:B + 3].cpu().numpy(), want, what=f"block {block} skip {prec}/{bm}x{bn}/s{sp}")
+            skips += 1
     h.set_precision(_hip.PREC_AUTO)
-    assert tried >= 130
+    assert tried >= 170 and skips >= 10
 
 
 def test_time_bias_rows(gpu_models):

@@ -26,7 +26,7 @@ ws = h.workspace(Bt, H, H)
 lib = _hip.load()
 names = engine.BLOCK_NAMES
 print(f"sf={sf} batch_total={Bt}: us (TF/s fp32-equivalent) per launch; prec/tile/splits")
-configs = [(p, bm, bn, sp) for p in (0, 1, 2) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 3, 9)]
+configs = [(p, bm, bn, sp) for p in (0, 1, 2) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 3, 4, 8, 9)]
 configs += [(3, bm, bn, sp) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 4, 8)]
 for j in range(8):
     for slot in range(3):
