@@ -200,7 +200,9 @@ ConvChoice heuristic_choice(int M, int n_p, int taps) {
   return c;
 }
 
-// sum of the split-K slabs in z order + the layer epilogue, float4 over channels
+// sum of the split-K slabs in z order + the layer epilogue, float4 over channels.  S = compile-time slab count
+// (all S loads of an element are issued before the first add); S = 0 walks p.splits at run time.
+template <int S>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p) {
   const int c4 = p.cout_p >> 2;
   const size_t total = (size_t)p.M * c4;
@@ -209,10 +211,20 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p
     const int n = (int)(i % c4) * 4;
     const size_t m = i / c4;
     const size_t o = m * p.cout_p + n;
-    float4 a = *reinterpret_cast<const float4 *>(p.slab + o);
-    for (int z = 1; z < p.splits; ++z) {
-      const float4 b = *reinterpret_cast<const float4 *>(p.slab + z * slab_stride + o);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    float4 a;
+    if (S > 0) {
+      float4 part[S > 0 ? S : 1];
+#pragma unroll
+      for (int z = 0; z < S; ++z) part[z] = *reinterpret_cast<const float4 *>(p.slab + z * slab_stride + o);
+      a = part[0];
+#pragma unroll
+      for (int z = 1; z < S; ++z) { a.x += part[z].x; a.y += part[z].y; a.z += part[z].z; a.w += part[z].w; }
+    } else {
+      a = *reinterpret_cast<const float4 *>(p.slab + o);
+      for (int z = 1; z < p.splits; ++z) {
+        const float4 b = *reinterpret_cast<const float4 *>(p.slab + z * slab_stride + o);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
     }
     const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n), sh = *reinterpret_cast<const float4 *>(p.shift + n);
     float4 v = make_float4(a.x * sc.x + sh.x, a.y * sc.y + sh.y, a.z * sc.z + sh.z, a.w * sc.w + sh.w);
@@ -242,9 +254,16 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p
 
 int launch_splitk_epilogue(const ConvParams &p, hipStream_t s) {
   const size_t total = (size_t)p.M * (p.cout_p / 4);
-  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   ProfileScope prof(KC_SPLITK_EPILOGUE, 0.0, 4.0 * p.M * p.cout_p * (p.splits + 1.0), s);
-  splitk_epilogue_kernel<<<blocks, 256, 0, s>>>(p);
+  switch (p.splits) {
+    case 2: splitk_epilogue_kernel<2><<<blocks, 256, 0, s>>>(p); break;
+    case 3: splitk_epilogue_kernel<3><<<blocks, 256, 0, s>>>(p); break;
+    case 4: splitk_epilogue_kernel<4><<<blocks, 256, 0, s>>>(p); break;
+    case 8: splitk_epilogue_kernel<8><<<blocks, 256, 0, s>>>(p); break;
+    case 9: splitk_epilogue_kernel<9><<<blocks, 256, 0, s>>>(p); break;
+    default: splitk_epilogue_kernel<0><<<blocks, 256, 0, s>>>(p); break;
+  }
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

@@ -26,26 +26,32 @@ __device__ inline void store_planes4(void *out_pl, size_t m, int c0, int cq, con
 // 16-channel-padded image (K = 144), and the centre taps (k = 9c+4) double as the NHWC image.
 __global__ void im2col3_kernel(const float *__restrict__ x, float *__restrict__ out, int B, int n_pass, int C, int H,
                                int W, int kp) {
-  const size_t total = (size_t)n_pass * B * H * W * kp;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int k = i % kp;
-    size_t pix = i / kp;
+  // one thread per (pixel, 4 consecutive k): 32-bit index math, one float4 store
+  const unsigned kq = (unsigned)kp >> 2;
+  const unsigned total = (unsigned)n_pass * B * H * W * kq;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned q = i % kq;
+    unsigned pix = i / kq;
     const int xx = pix % W; pix /= W;
     const int yy = pix % H;
-    const int b = (pix / H) % B;
-    float v = 0.f;
-    if (k < 9 * C) {
+    const unsigned b = (pix / H) % B;
+    const float *img = x + (size_t)b * C * H * W;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = (int)q * 4 + e;
       const int c = k / 9, tap = k - 9 * c;
       const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
-      if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = x[(((size_t)b * C + c) * H + sy) * W + sx];
+      v[e] = (k < 9 * C && sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[(c * H + sy) * W + sx] : 0.f;
     }
-    out[i] = v;
+    reinterpret_cast<float4 *>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
 int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, int W, int kp, hipStream_t s) {
-  const size_t total = (size_t)n_pass * B * H * W * kp;
-  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  const size_t total = (size_t)n_pass * B * H * W * (kp / 4);
+  if (kp % 4 || total >= (1ull << 32)) return DT_E_SHAPE;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   ProfileScope prof(KC_IM2COL, 0.0, 4.0 * B * H * W * (C + (double)n_pass * kp), s);
   im2col3_kernel<<<blocks, 256, 0, s>>>(x, out, B, n_pass, C, H, W, kp);
   DT_LAUNCH_CHECK();
