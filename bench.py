@@ -68,6 +68,17 @@ class Workload:
         cfg.image_size, cfg.timesteps, cfg.sample_steps = H, T, T
         self.models = [make_model(DiffusionUNet, cfg, sf).to(device) for sf in (TEACHER_SF, STUDENT_SF)]
         self.handles = [engine.UNetHandle.for_module(m) for m in self.models]
+        # Samples are independent, so a model's batch may run as several contiguous sub-batches, each with its own
+        # handle (workspace), HIP stream and host thread: DT_BENCH_PARTS="teacher_parts,student_parts".  Default:
+        # the teacher (4x the student's FLOPs) as two halves, so three loops of similar length share the GPU
+        # (measured 1,1: 259 k  2,1: 270 k  2,2: 242 k  3,1: 225 k trajectory-timesteps/s)
+        parts = [int(v) for v in os.environ.get("DT_BENCH_PARTS", "2,1").split(",")] if concurrent else [1, 1]
+        self.parts = []
+        for i, n in enumerate(parts):
+            n = max(1, min(n, batch))
+            bounds = [(batch * k // n, batch * (k + 1) // n) for k in range(n)]
+            hs = [self.handles[i]] + [engine.UNetHandle(self.models[i].state_dict(), device) for _ in range(n - 1)]
+            self.parts.append(list(zip(hs, bounds)))
         self.E = C * H * H
         idx = timestep_indices(T, T)
         self.coef = psample_coefficients(get_diffusion_params(T, cfg), idx)
@@ -82,13 +93,16 @@ class Workload:
             k += int(flag)
         self.tb = [h.time_bias([i for i in idx for _ in (0, 1)], [COND_NONE, COND_ONE] * T) for h in self.handles]
         self.traj = [torch.empty(T + 1, batch, self.E, device=device) for _ in self.handles]
-        for h, tb in zip(self.handles, self.tb):
-            # tile / split / arithmetic autotuning happens here, one model at a time on an idle GPU
-            h.forward(self.x_T.reshape(batch, C, H, H), tb[:2].contiguous(), 2, batch, tune=True)
+        self.part_traj = [[self.traj[i] if len(ps) == 1 else torch.empty(T + 1, hi - lo, self.E, device=device)
+                           for (_, (lo, hi)) in ps] for i, ps in enumerate(self.parts)]
+        for i, ps in enumerate(self.parts):
+            for h, (lo, hi) in ps:
+                # tile / split / arithmetic autotuning happens here, one launch shape at a time on an idle GPU
+                h.forward(self.x_T[lo:hi].reshape(hi - lo, C, H, H), self.tb[i][:2].contiguous(), 2, hi - lo, tune=True)
         torch.cuda.synchronize()
         self.choices = None
         self.concurrent = concurrent
-        self.streams = [torch.cuda.Stream(device=device) for _ in self.handles]
+        self.streams = [[torch.cuda.Stream(device=device) for _ in ps] for ps in self.parts]
 
     def step(self, world, counts):
         """One pass of the hot path: both samplers, the metric reductions, the metric all-gather."""
@@ -96,11 +110,11 @@ class Workload:
         from distillation_trajectories_amd.grid import all_gather_rows
         eng = self.engine
 
-        def run(i):
-            h, tb, traj = self.handles[i], self.tb[i], self.traj[i]
-            traj[0].copy_(self.x_T)
-            h.sample(RULE_PSAMPLE, traj, H, H, tb, 2, self.coef, self.has_noise, z=self.z, z_shift=self.z_shift,
-                     w_scalar=GUIDANCE)
+        def run(i, k=0):
+            (h, (lo, hi)), tb, traj = self.parts[i][k], self.tb[i], self.part_traj[i][k]
+            traj[0].copy_(self.x_T[lo:hi])
+            h.sample(RULE_PSAMPLE, traj, H, H, tb, 2, self.coef, self.has_noise, z=self.z,
+                     z_shift=[v + lo for v in self.z_shift], w_scalar=GUIDANCE)
         if self.concurrent:
             # teacher and student loops are independent: one HIP stream + one host thread each (the C call
             # releases the GIL), so the small spatial levels of one model overlap the other's work
@@ -108,20 +122,27 @@ class Workload:
             ready = torch.cuda.Event()
             ready.record(main)
 
-            def worker(i):
-                with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i]):
-                    self.streams[i].wait_event(ready)
-                    run(i)
-            threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(self.handles))]
+            def worker(i, k):
+                with torch.cuda.device(self.device), torch.cuda.stream(self.streams[i][k]):
+                    self.streams[i][k].wait_event(ready)
+                    run(i, k)
+            threads = [threading.Thread(target=worker, args=(i, k)) for i, ps in enumerate(self.parts) for k in range(len(ps))]
             for t in threads:
                 t.start()
             for t in threads:
                 t.join()
-            for st in self.streams:
-                main.wait_stream(st)
+            for sts in self.streams:
+                for st in sts:
+                    main.wait_stream(st)
+            for i, ps in enumerate(self.parts):
+                if len(ps) > 1:                      # reassemble [T+1, B, E] for the pairwise metrics
+                    torch.cat(self.part_traj[i], dim=1, out=self.traj[i])
         else:
-            for i in range(len(self.handles)):
-                run(i)
+            for i, ps in enumerate(self.parts):
+                for k in range(len(ps)):
+                    run(i, k)
+                if len(ps) > 1:
+                    torch.cat(self.part_traj[i], dim=1, out=self.traj[i])
         sums = eng.device_metric_sums(self.traj[0], self.traj[1])          # [B, T+1, 4] float64
         w1 = eng.device_wasserstein(self.traj[0], self.traj[1])            # [B, T+1]   float64
         local = torch.cat([sums.reshape(self.B, -1), w1], dim=1)
@@ -130,8 +151,8 @@ class Workload:
         n = T + 1
         vals = eng.batch_scalar_metrics(host[:, : 4 * n].reshape(-1, n, 4), host[:, 4 * n:], H * H, self.E)
         if self.choices is None:
-            self.choices = {f"sf={sf}": [list(c) for c in h.conv_choices(2 * self.B, H, H)]
-                            for sf, h in zip((TEACHER_SF, STUDENT_SF), self.handles)}
+            self.choices = {f"sf={sf}": [list(c) for c in ps[0][0].conv_choices(2 * (ps[0][1][1] - ps[0][1][0]), H, H)]
+                            for sf, ps in zip((TEACHER_SF, STUDENT_SF), self.parts)}
         return vals
 
 
@@ -264,7 +285,8 @@ def main():
         "config": {"workload": "configs[1]: teacher sf=1.0 vs student sf=0.5, 16x16x3, T=50, batch 256/GPU, "
                                "p_sample_loop CFG (2 U-Net passes/step, w=1.0) + trajectory metrics of the 256 pairs",
                    "batch_per_gpu": args.batch, "timesteps": T, "image": [C, H, H], "guidance_scale": GUIDANCE,
-                   "unet_passes_per_step": 2, "parallelism": f"sample-sharded x{world}, RCCL all-gather of metrics"},
+                   "unet_passes_per_step": 2, "parallelism": f"sample-sharded x{world}, RCCL all-gather of metrics",
+                   "streams_per_gpu": {"teacher_sub_batches": len(wl.parts[0]), "student_sub_batches": len(wl.parts[1])}},
         "per_gpu": round(value / world, 1),
         "metric_check": {"mean_endpoint_distance": float(np.mean(vals["endpoint_distance"])),
                          "mean_wasserstein": float(np.mean(vals["mean_wasserstein"])),
@@ -291,8 +313,8 @@ def main():
                            "all_conv_vs_native_fp32_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                            "timed_with": f"hipEventRecord pairs around every launch, second pass of the same {args.steps} "
                                          f"steps on ONE stream ({profiled_elapsed / args.steps * 1e3:.1f} ms/step with events vs "
-                                         f"{elapsed / args.steps * 1e3:.1f} ms/step in the timed region, where the teacher and "
-                                         "student loops run on two streams)"}
+                                         f"{elapsed / args.steps * 1e3:.1f} ms/step in the timed region, where the teacher's "
+                                         "sub-batches and the student loop each run on their own stream)"}
         out["tile_choices"] = wl.choices
         out["kernels"] = {n: {"launches": k["launches"], "ms": round(k["ms"], 3),
                               "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["flops"] else None,
