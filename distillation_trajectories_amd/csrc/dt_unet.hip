@@ -522,7 +522,10 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
             // a fused conv2 also saves the separate skip launch measured for slot 0
             // candidates are visited from small to large tiles: a later (larger-tile, fewer-workgroup) one wins
             // ties within 2 % so that run-to-run timing noise does not flip the plan
-            const float cost = ms_min + (fuse ? 0.f : (can_fuse ? skip_ms : 0.f));
+            // launches are timed on an idle GPU, where extra workgroups are free; in the sampler other streams fill
+            // idle CUs anyway, so a split (slab traffic + one more launch) must win by a margin to be taken
+            static const float split_margin = getenv("DT_TUNE_SPLIT_MARGIN") ? (float)atof(getenv("DT_TUNE_SPLIT_MARGIN")) : 1.1f;
+            const float cost = (ms_min + (fuse ? 0.f : (can_fuse ? skip_ms : 0.f))) * (sp > 1 ? split_margin : 1.0f);
             if (cost < best_ms * 1.02f) { best_ms = cost < best_ms ? cost : best_ms; best = ConvChoice{bm, bn, sp, prec, fuse}; }
           }
         }
