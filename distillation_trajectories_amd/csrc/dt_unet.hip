@@ -7,6 +7,7 @@
 //   up+cat(enc4) -> dec3 @H/8 -> up+cat(enc3) -> dec2 @H/4 -> up+cat(enc2) -> dec1 @H/2 -> up + 1x1 head @H
 // Each residual block is up to three implicit-GEMM launches (1x1 skip, conv1, conv2) whose epilogues
 // carry BN/ReLU/time-bias/residual, so a forward is 8 blocks * (2..3) + 4 pools + 3 upcats + 2 = ~32 launches.
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -101,8 +102,16 @@ struct TunedShape {
   ConvChoice c[kBlocks][3];
 };
 
+// an instantiated hipGraph of one dt_sample_trajectory call (every launch of the loop), keyed by all its arguments
+struct LoopGraph {
+  std::vector<unsigned char> key;
+  hipGraphExec_t exec;
+  hipGraph_t graph;
+};
+
 struct dt_unet {
   std::vector<TunedShape> tuned;
+  std::vector<LoopGraph> graphs;   // replay cache of the sampler loop; dropped whenever the launch plan changes
   int precision;          // DT_PREC_*: which convolution arithmetic the heuristic / autotuner may use
   bool planes;            // producers also emit bf16 plane twins, enabling the LDS-DMA conv (prec 2)
   float *zero_page;       // 256 B of zeros inside the slab (source of out-of-image DMA lanes)
@@ -166,6 +175,11 @@ Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
   p.lowres = b.take((size_t)Bt * (H / 2) * (W / 2) * 4);
   p.total = b.off;
   return p;
+}
+
+void drop_graphs(dt_unet *u) {
+  for (LoopGraph &g : u->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+  u->graphs.clear();
 }
 
 const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W) {
@@ -431,6 +445,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
 
 void dt_unet_destroy(dt_unet *h) {
   if (!h) return;
+  drop_graphs(h);
   if (h->slab) (void)hipFree(h->slab);
   delete h;
 }
@@ -538,8 +553,9 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
   (void)hipEventDestroy(e1);
   if (st != DT_OK) return st;
   for (TunedShape &old : h->tuned)
-    if (old.Bt == t.Bt && old.H == t.H && old.W == t.W) { old = t; return DT_OK; }
+    if (old.Bt == t.Bt && old.H == t.H && old.W == t.W) { old = t; drop_graphs(h); return DT_OK; }
   h->tuned.push_back(t);
+  drop_graphs(h);
   return DT_OK;
 }
 
@@ -580,6 +596,7 @@ int dt_unet_set_precision(dt_unet *h, int precision) {
   if (!h) return DT_E_NULL;
   if (precision < DT_PREC_FP32 || precision > DT_PREC_AUTO_PLANES) return DT_E_ARG;
   h->tuned.clear();                               // choices are per arithmetic mode: back to the heuristic plan
+  drop_graphs(h);
   h->precision = precision;
   h->planes = precision == DT_PREC_AUTO_PLANES;   // changes the workspace size: re-query dt_unet_workspace_bytes
   return DT_OK;
@@ -637,6 +654,7 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
     t = &h->tuned.back();
   }
   t->c[block][slot] = ConvChoice{bm, bn, splits, prec, fuse};
+  drop_graphs(h);
   return DT_OK;
 }
 
@@ -655,13 +673,10 @@ int dt_cfg_update(int rule, const float *x, const float *eu, const float *ec, co
   return launch_cfg_update(rule, x, eu, ec, z, z_row, 0, coef, has_noise, w, w_scalar, out, B, E, (hipStream_t)stream);
 }
 
-int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, int W, int n_steps, const float *tb,
-                         const float *coef, const int32_t *has_noise, const float *z, const int32_t *z_row,
-                         const int64_t *z_shift, const float *w, float w_scalar, float *traj, float *eps_scratch,
-                         void *ws, size_t ws_bytes, void *stream) {
-  if (!h || !tb || !coef || !has_noise || !traj || !eps_scratch || !ws) return DT_E_NULL;
-  if (n_pass < 1 || n_pass > 2 || n_steps < 0 || rule < 0 || rule > DT_RULE_MANAGER) return DT_E_ARG;
-  hipStream_t s = (hipStream_t)stream;
+static int sample_loop(const dt_unet *h, int rule, int B, int n_pass, int H, int W, int n_steps, const float *tb,
+                       const float *coef, const int32_t *has_noise, const float *z, const int32_t *z_row,
+                       const int64_t *z_shift, const float *w, float w_scalar, float *traj, float *eps_scratch,
+                       void *ws, size_t ws_bytes, hipStream_t s) {
   const int E = h->desc.channels * H * W;
   const size_t slot = (size_t)B * E;
   for (int i = 0; i < n_steps; ++i) {
@@ -678,6 +693,56 @@ int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, i
     if (st) return st;
   }
   return DT_OK;
+}
+
+/* The loop is a fixed chain of (n_steps x ~45) launches whose arguments depend only on this call's arguments, so a
+ * repeated call (same buffers, same schedule) can replay an instantiated hipGraph instead of re-issuing each launch.
+ * Opt-in with DT_GRAPH=1: measured on MI355X / ROCm 7.2 the replay is time-neutral (batch 8: 31.5 vs 31.5 ms per
+ * 100 forwards, batch 256: 94.9 vs 94.9 ms/step) -- the loop is bound by the GPU-side latency of its dependent
+ * kernels (~6 us each at batch 8), not by host launch cost, which the host threads already hide. */
+int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, int W, int n_steps, const float *tb,
+                         const float *coef, const int32_t *has_noise, const float *z, const int32_t *z_row,
+                         const int64_t *z_shift, const float *w, float w_scalar, float *traj, float *eps_scratch,
+                         void *ws, size_t ws_bytes, void *stream) {
+  if (!h || !tb || !coef || !has_noise || !traj || !eps_scratch || !ws) return DT_E_NULL;
+  if (n_pass < 1 || n_pass > 2 || n_steps < 0 || rule < 0 || rule > DT_RULE_MANAGER) return DT_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const char *genv = getenv("DT_GRAPH");
+  const bool use_graph = genv && atoi(genv) != 0;
+  if (!use_graph || g_prof.on || n_steps < 4)
+    return sample_loop(h, rule, B, n_pass, H, W, n_steps, tb, coef, has_noise, z, z_row, z_shift, w, w_scalar, traj,
+                       eps_scratch, ws, ws_bytes, s);
+  // ---- key: every argument by value (the small host arrays by content)
+  std::vector<unsigned char> key;
+  auto put = [&key](const void *p, size_t n) { const unsigned char *c = (const unsigned char *)p; key.insert(key.end(), c, c + n); };
+  const int ints[7] = {rule, B, n_pass, H, W, n_steps, z_shift ? 1 : 0};
+  const void *ptrs[8] = {tb, z, z_row, w, traj, eps_scratch, ws, (const void *)s};
+  put(ints, sizeof(ints)); put(ptrs, sizeof(ptrs)); put(&w_scalar, sizeof(w_scalar)); put(&ws_bytes, sizeof(ws_bytes));
+  put(coef, sizeof(float) * 4 * n_steps); put(has_noise, sizeof(int32_t) * n_steps);
+  if (z_shift) put(z_shift, sizeof(int64_t) * n_steps);
+  dt_unet *hm = const_cast<dt_unet *>(h);   // the cache is not part of the handle's logical state
+  for (const LoopGraph &g : hm->graphs)
+    if (g.key == key) return (int)hipGraphLaunch(g.exec, s);
+  // ---- first call with these arguments: capture the loop, instantiate, keep (at most 8 per handle)
+  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {   // stream cannot be captured (e.g. the legacy default stream): plain launches
+    (void)hipGetLastError();
+    return sample_loop(h, rule, B, n_pass, H, W, n_steps, tb, coef, has_noise, z, z_row, z_shift, w, w_scalar, traj,
+                       eps_scratch, ws, ws_bytes, s);
+  }
+  const int st = sample_loop(h, rule, B, n_pass, H, W, n_steps, tb, coef, has_noise, z, z_row, z_shift, w, w_scalar, traj,
+                             eps_scratch, ws, ws_bytes, s);
+  LoopGraph g{};
+  e = hipStreamEndCapture(s, &g.graph);
+  if (st != DT_OK) { if (e == hipSuccess && g.graph) (void)hipGraphDestroy(g.graph); return st; }
+  if (e != hipSuccess) return (int)e;
+  e = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g.graph); return (int)e; }
+  g.key = std::move(key);
+  if (hm->graphs.size() >= 8) { (void)hipGraphExecDestroy(hm->graphs.front().exec); (void)hipGraphDestroy(hm->graphs.front().graph); hm->graphs.erase(hm->graphs.begin()); }
+  hm->graphs.push_back(std::move(g));
+  if (getenv("DT_GRAPH_DEBUG")) fprintf(stderr, "[dt_hip] captured sampler loop: %d steps, batch %d -> graph #%zu\n", n_steps, B, hm->graphs.size());
+  return (int)hipGraphLaunch(hm->graphs.back().exec, s);
 }
 
 int dt_profile_begin(void) {

@@ -206,7 +206,12 @@ class UNetHandle:
         coef_c = (c_float * (4 * n_steps))(*[float(v) for row in coef for v in (list(row) + [0.0] * 4)[:4]])
         noise_c = (c_int32 * n_steps)(*[int(bool(v)) for v in has_noise])
         shift_c = (c_int64 * n_steps)(*[int(v) for v in (z_shift if z_shift is not None else [0] * n_steps)])
-        eps = torch.empty(n_pass, B, traj.shape[2], dtype=torch.float32, device=self.device)
+        # scratch for the predictions lives with the handle: stable addresses let the library replay its
+        # captured hipGraph of the loop on repeated calls
+        ekey = ("eps", n_pass, B, traj.shape[2])
+        eps = self._ws.get(ekey)
+        if eps is None:
+            eps = self._ws[ekey] = torch.empty(n_pass, B, traj.shape[2], dtype=torch.float32, device=self.device)
         ws = self.workspace(n_pass * B, H, W)
         if n_steps and self._wants_tuning(n_pass * B, H, W, None):
             self.forward(traj[0].reshape(B, self.channels, H, W), tb[:n_pass].contiguous(), n_pass, B, tune=True)

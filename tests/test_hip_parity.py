@@ -179,6 +179,39 @@ def test_conv_tile_variants_match_oracle(gpu_models):
     assert tried >= 170 and skips >= 10
 
 
+def test_sampler_graph_replay_is_bit_exact(gpu_models, monkeypatch):
+    """DT_GRAPH=1: dt_sample_trajectory captures the loop into a hipGraph on a side stream and replays it on the
+    next call with the same arguments; both must equal the plain launch sequence bit for bit."""
+    from distillation_trajectories_amd.utils.diffusion import get_diffusion_params, psample_coefficients, timestep_indices
+    from distillation_trajectories_amd.config import Config
+    m = gpu_models(0.5)
+    h = engine.UNetHandle.for_module(m)
+    cfg = Config(); cfg.image_size, cfg.timesteps = 16, 50
+    idx = timestep_indices(50, 10)
+    coef = psample_coefficients(get_diffusion_params(50, cfg), idx)
+    noise = [i > 0 for i in idx]
+    B, E = 6, 3 * 16 * 16
+    g = torch.Generator().manual_seed(11)
+    x_T, z = torch.randn(B, E, generator=g).to(DEV), torch.randn(len(idx) * B, E, generator=g).to(DEV)
+    tb = h.time_bias([i for i in idx for _ in (0, 1)], [_hip.COND_NONE, _hip.COND_ONE] * len(idx))
+    shift = [k * B for k in range(len(idx))]
+
+    def run(traj):
+        traj[0].copy_(x_T)
+        h.sample(_hip.RULE_PSAMPLE, traj, 16, 16, tb, 2, coef, noise, z=z, z_shift=shift, w_scalar=3.0)
+        return traj
+    plain = run(torch.empty(len(idx) + 1, B, E, device=DEV)).clone()
+    monkeypatch.setenv("DT_GRAPH", "1")
+    side = torch.cuda.Stream()
+    traj = torch.empty(len(idx) + 1, B, E, device=DEV)
+    with torch.cuda.stream(side):
+        first = run(traj).clone()         # capture + first launch
+        traj.zero_()
+        second = run(traj).clone()        # replay
+    side.synchronize()
+    assert torch.equal(first, plain) and torch.equal(second, plain)
+
+
 def test_time_bias_rows(gpu_models):
     m = gpu_models(0.2)
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
