@@ -6,8 +6,9 @@
 // tile's rows PLUS a halo of W+1 pixels on either side in LDS as three bf16 planes:
 //      strip row s  <->  pixel m0 - (W+1) + s,      s in [0, BM + 2(W+1))
 // and tap (dy, dx) of output row r reads strip row r + (W+1) + dy*W + dx -- the same LDS image at a shifted row.
-// Taps that fall outside the picture (zero padding, also across picture boundaries inside a tile) read a
-// dedicated all-zero strip row instead; validity is a 9-bit mask per fragment row, computed once.
+// Taps that fall outside the picture (zero padding, also across picture boundaries inside a tile) read one of
+// sixteen all-zero rows instead (the one with the same bank as the real row would have: no conflicts); validity
+// is a 9-bit mask per fragment row, computed once.
 // Per chunk: one strip load/split/write, then nine steps that only stage the 3 x BN x 16 weight tile of their
 // tap (double buffered) and run 24 MFMAs per wave.  ds_read_b128 stays conflict-free at any shift because the
 // half-swap swizzle is a function of the strip row (rows 8 apart always differ in it).
@@ -33,9 +34,10 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
   constexpr int PLANE_B = BN * 16, STAGE_B = 3 * PLANE_B;         // bf16 elements
   constexpr int AP = 2;                                            // strip items (row, k-half) per thread
   const int halo = p.W + 1;
-  const int R = BM + 2 * halo;                                     // strip rows; row R is all zeros
-  const int PLANE_A = (R + 1) * 16;
-  __bf16 *As = strip_lds;                                          // [3][R+1][16]
+  const int R = BM + 2 * halo;                                     // strip rows
+  const int RZ = (R + 7) & ~7;                                     // 16 all-zero rows start here (multiple of 8)
+  const int PLANE_A = (RZ + 16) * 16;
+  __bf16 *As = strip_lds;                                          // [3][RZ+16][16]
   __bf16 *Bs = strip_lds + 3 * PLANE_A;                            // [2][3][BN][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,7 +95,6 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
     const int row = wn * (NI * 32) + ni * 32 + l31;
     b_frag[ni] = row * 16 + ((half ^ ((row >> 3) & 1)) << 3);
   }
-  const int zero_e = R * 16 + (half << 3);
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
   // ---- prologue: strip of chunk 0, weights of step 0, the zero row
   load_strip(0);
   load_b(0, 0);
-  if (tid < 6) *reinterpret_cast<u32x4 *>(As + (tid >> 1) * PLANE_A + R * 16 + (tid & 1) * 8) = u32x4{0u, 0u, 0u, 0u};
+  if (tid < 96) *reinterpret_cast<u32x4 *>(As + (tid >> 5) * PLANE_A + RZ * 16 + (tid & 31) * 8) = u32x4{0u, 0u, 0u, 0u};
   write_strip();
   write_b(0);
   __syncthreads();
@@ -176,9 +177,11 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
       int a_e[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
+        // an out-of-picture tap reads zero row RZ + (srow & 15) at the same physical half: the bank a lane hits is
+        // the one its in-picture read would hit, so any mix of the two stays conflict-free
         const int srow = a_row[mi] + shift;
-        const int e = srow * 16 + ((half ^ ((srow >> 3) & 1)) << 3);
-        a_e[mi] = ((a_mask[mi] >> tt) & 1u) ? e : zero_e;
+        const int lrow = ((a_mask[mi] >> tt) & 1u) ? srow : RZ + (srow & 15);
+        a_e[mi] = lrow * 16 + ((half ^ ((srow >> 3) & 1)) << 3);
       }
       const __bf16 *B = Bs + (step & 1) * STAGE_B;
       bf16x8 fb[NI][3];
@@ -236,7 +239,7 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, hipStream_t s) {
   if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 strip items per thread cover BM + 2(W+1) <= 256 rows
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   const int R = bm + 2 * (p.W + 1);
-  const size_t lds = ((size_t)3 * (R + 1) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
+  const size_t lds = ((size_t)3 * (((R + 7) & ~7) + 16) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
   if (lds > 65536) return DT_E_SHAPE;
   if (p.ablate && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
     switch (p.ablate) {
