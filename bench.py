@@ -69,10 +69,11 @@ class Workload:
         self.models = [make_model(DiffusionUNet, cfg, sf).to(device) for sf in (TEACHER_SF, STUDENT_SF)]
         self.handles = [engine.UNetHandle.for_module(m) for m in self.models]
         # Samples are independent, so a model's batch may run as several contiguous sub-batches, each with its own
-        # handle (workspace), HIP stream and host thread: DT_BENCH_PARTS="teacher_parts,student_parts".  Default:
-        # the teacher (4x the student's FLOPs) as two halves, so three loops of similar length share the GPU
-        # (measured 1,1: 259 k  2,1: 270 k  2,2: 242 k  3,1: 225 k trajectory-timesteps/s)
-        parts = [int(v) for v in os.environ.get("DT_BENCH_PARTS", "2,1").split(",")] if concurrent else [1, 1]
+        # handle (workspace), HIP stream and host thread: DT_BENCH_PARTS="teacher_parts,student_parts".  Measured
+        # 1,1: 259-262 k  2,1: 270-274 k  2,2: 242 k  3,1: 225 k trajectory-timesteps/s.  The default stays 1,1:
+        # the teacher as two halves buys 4 % of wall time by overlap but halves every teacher launch, so the
+        # per-launch (roofline) figures then describe smaller, less efficient launches (all convs 126 vs 145 TF/s).
+        parts = [int(v) for v in os.environ.get("DT_BENCH_PARTS", "1,1").split(",")]   # --serial: same sub-batches, one stream
         self.parts = []
         for i, n in enumerate(parts):
             n = max(1, min(n, batch))
@@ -293,28 +294,43 @@ def main():
                          "pairs": int(len(vals["mse"]))},
     }
     if kernels:
-        dom_name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+        # A kernel = one __global__ template; its tile instantiations <BM,BN> are the same code on other tile sizes and
+        # which of them the autotuner picks per layer varies run to run, so the roofline entry is per template.
+        groups = {}
+        for n, k in kernels.items():
+            g = groups.setdefault(n.split("<")[0], {"ms": 0.0, "flops": 0.0, "launches": 0, "members": {}})
+            g["ms"] += k["ms"]; g["flops"] += k["flops"]; g["launches"] += k["launches"]; g["members"][n] = k
+        dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         total_ms = sum(k["ms"] for k in kernels.values())
         conv = {n: k for n, k in kernels.items() if n.startswith(("conv_gemm", "conv_strip"))}
         conv_ms, conv_fl = sum(k["ms"] for k in conv.values()), sum(k["flops"] for k in conv.values())
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         split = "bf16x6" in dom_name
         peak = PEAK_BF16_MFMA_TFLOPS / PLANE_PRODUCTS if split else PEAK_FP32_MFMA_TFLOPS
-        out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
+        traffic = None
+        per = {n: traffic_from_profiles(n) for n in dom["members"]}
+        if all(per.values()):
+            traffic = {"hbm_bytes_per_launch": int(sum(per[n]["hbm_bytes_per_launch"] * k["launches"] for n, k in dom["members"].items())
+                                                   / dom["launches"]),
+                       "per_instantiation": {n: per[n]["hbm_bytes_per_launch"] for n in per}, "method": next(iter(per.values()))["method"]}
+        out["roofline"] = {"bound": "mfma", "kernel": dom_name + "<BM,BN>", "achieved": round(achieved, 2),
                            "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                            "peak_basis": ("dense bf16 MFMA 2500 TF/s / 6 plane products per fp32-accurate product; "
                                           f"issued bf16 MFMA rate {achieved * PLANE_PRODUCTS:.0f} TF/s; native fp32 MFMA "
                                           f"peak is {PEAK_FP32_MFMA_TFLOPS} TF/s") if split else "dense fp32 MFMA",
-                           "traffic": traffic_from_profiles(dom_name), "launches": dom["launches"],
+                           "traffic": traffic, "launches": dom["launches"],
                            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                            "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+                           "instantiations": {n: {"launches": k["launches"], "avg_launch_us": round(k["ms"] / k["launches"] * 1e3, 2),
+                                                  "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2)}
+                                              for n, k in sorted(dom["members"].items(), key=lambda kv: -kv[1]["ms"])},
                            "share_of_kernel_time": round(dom["ms"] / total_ms, 3),
                            "all_conv_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                            "all_conv_vs_native_fp32_peak": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                            "timed_with": f"hipEventRecord pairs around every launch, second pass of the same {args.steps} "
                                          f"steps on ONE stream ({profiled_elapsed / args.steps * 1e3:.1f} ms/step with events vs "
-                                         f"{elapsed / args.steps * 1e3:.1f} ms/step in the timed region, where the teacher's "
-                                         "sub-batches and the student loop each run on their own stream)"}
+                                         f"{elapsed / args.steps * 1e3:.1f} ms/step in the timed region, where the teacher and "
+                                         "student loops (and sub-batches, if any) each run on their own stream)"}
         out["tile_choices"] = wl.choices
         out["kernels"] = {n: {"launches": k["launches"], "ms": round(k["ms"], 3),
                               "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["flops"] else None,

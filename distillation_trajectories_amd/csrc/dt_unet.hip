@@ -504,17 +504,23 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       const bool can_fuse = slot == 2 && j > 0 && h->blk[j].has_res;
       const BlockW &kw = h->blk[j];
       const bool full3x3 = p.ksize == 3 && p.tap_hi - p.tap_lo == 9;
+      // Kernel families worth timing (the search is paid once per model and shape, so it is pruned to what the
+      // per-layer tables show can win): exact-fp32 mode -> the fp32-MFMA kernel only; otherwise the strip kernel
+      // for full 3x3 walks, the plain split-bf16 kernel for everything else, the LDS-DMA kernel where twins exist.
       for (int prec = 0; prec <= 3; ++prec) {
-        if ((h->precision == DT_PREC_FP32 && prec >= 1) || (h->precision == DT_PREC_SPLIT_BF16 && prec == 0)) continue;
+        if (h->precision == DT_PREC_FP32 ? prec != 0 : prec == 0) continue;
         if (prec == 2 && !p.in_pl) continue;
         if (prec == 3 && !full3x3) continue;
+        if (prec == 1 && full3x3) continue;
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
           // 3x3 walks split by taps 1/3/9; the strip kernel and single-tap layers by channel chunks 1/2/4/8
+          const long long tiles = (long long)((p.M + bm - 1) / bm) * (p.n_p / bn);
           for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= ((prec == 3 || !walk9) ? 2 : 3))
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
             if ((prec == 3 || !walk9) && (p.cin_p >> 4) % sp) continue;
+            if (sp > 1 && tiles * (sp / 2) >= 1024) continue;          // already >= 4 workgroups per CU without this split
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
             q.w = prec ? (slot == 0 ? kw.wrb : (slot == 1 ? kw.w1b : kw.w2b)) : (slot == 0 ? kw.wr : (slot == 1 ? kw.w1 : kw.w2));
@@ -525,7 +531,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
               if (prec == 2 && !q.in2_pl) continue;
             }
             float ms_min = 1e30f;
-            for (int rep = 0; rep < 5 && st == DT_OK; ++rep) {
+            for (int rep = 0; rep < 4 && st == DT_OK; ++rep) {
               (void)hipEventRecord(e0, s);
               st = launch_conv(q, s);
               (void)hipEventRecord(e1, s);
