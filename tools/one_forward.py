@@ -1,6 +1,6 @@
 """One teacher forward at the bench shape (for rocprofv3 --pmc passes)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from distillation_trajectories_amd import _hip, engine
 from distillation_trajectories_amd.config import Config

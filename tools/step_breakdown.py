@@ -1,6 +1,6 @@
 """Where one bench step spends its wall time: sampler loops vs metric kernels vs host-side metric assembly."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 torch.cuda.set_device(0)
