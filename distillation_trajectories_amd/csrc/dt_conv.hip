@@ -152,14 +152,14 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
   const bool tall_m = bm == 128, wide_n = bn == 128;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   if (p.splits < 1 || (p.splits > 1 && !p.slab)) return DT_E_ARG;
-  if (p.prec == 3 ? ((p.cin_p >> 4) % p.splits != 0) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % p.splits != 0)) return DT_E_ARG;
+  if (p.prec >= 3 ? ((p.cin_p >> 4) % (p.splits * (p.prec == 4 ? 2 : 1)) != 0) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % p.splits != 0)) return DT_E_ARG;
   // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
   if (p.in2 && (p.splits != 1 || !p.w2 || !p.bias2 || p.cin2_p % 16)) return DT_E_ARG;
   const double flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));
-  if (p.prec == 3) {
+  if (p.prec >= 3) {
     ProfileScope prof(tall_m ? (wide_n ? KC_CONVS_128x128 : KC_CONVS_128x64) : (wide_n ? KC_CONVS_64x128 : KC_CONVS_64x64),
                       flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
-    const int st = launch_conv_strip(p, bm, bn, s);
+    const int st = launch_conv_strip(p, bm, bn, p.prec == 4 ? 2 : 1, s);
     if (st) return st;
   } else if (p.prec == 2) {
     ProfileScope prof(tall_m ? (wide_n ? KC_CONVD_128x128 : KC_CONVD_128x64) : (wide_n ? KC_CONVD_64x128 : KC_CONVD_64x64),

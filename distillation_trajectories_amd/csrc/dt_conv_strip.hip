@@ -27,8 +27,10 @@ extern __shared__ __attribute__((aligned(16))) __bf16 strip_lds[];
 
 // ABL != 0: timing experiments (wrong results): 1 no per-tap barrier, 2 no weight staging, 3 no MFMA,
 // 4 no fragment reads after the first step, 5 no strip re-staging
-template <int BM, int BN, int ABL = 0>
-__global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvParams p) {
+// KC = 16-channel chunks staged and multiplied per step (1 or 2): KC = 2 halves the barriers and doubles the
+// MFMAs between them at twice the LDS footprint and staging registers (2 waves/SIMD instead of 3).
+template <int BM, int BN, int ABL = 0, int KC = 1>
+__global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel(const ConvParams p) {
   constexpr int WN = 2, NT = 256;
   constexpr int MI = BM / 64, NI = BN / 64;
   constexpr int PLANE_B = BN * 16, STAGE_B = 3 * PLANE_B;         // bf16 elements
@@ -37,8 +39,8 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
   const int R = BM + 2 * halo;                                     // strip rows
   const int RZ = (R + 7) & ~7;                                     // 16 all-zero rows start here (multiple of 8)
   const int PLANE_A = (RZ + 16) * 16;
-  __bf16 *As = strip_lds;                                          // [3][RZ+16][16]
-  __bf16 *Bs = strip_lds + 3 * PLANE_A;                            // [2][3][BN][16]
+  __bf16 *As = strip_lds;                                          // [KC][3][RZ+16][16]
+  __bf16 *Bs = strip_lds + KC * 3 * PLANE_A;                       // [2][KC][3][BN][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -104,60 +106,69 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int n_main = CC / p.splits;                                // channel chunks of this z slice
-  const int cc0 = blockIdx.z * n_main;
-  const int n_chunks = n_main + (p.in2 ? (p.cin2_p >> 4) : 0);
+  const int n_main = CC / p.splits / KC;                           // steps-worth of KC channel chunks in this z slice
+  const int cc0 = blockIdx.z * n_main * KC;
+  const int n_chunks = n_main + (p.in2 ? (p.cin2_p >> 4) / KC : 0);
 
-  f32x4 sa0[AP], sa1[AP];
-  u32x4 rb[3];
+  f32x4 sa0[KC][AP], sa1[KC][AP];
+  u32x4 rb[KC][3];
   auto load_strip = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
     for (int i = 0; i < AP; ++i) {
-      sa0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; sa1[i] = sa0[i];
+      sa0[kk][i] = f32x4{0.f, 0.f, 0.f, 0.f}; sa1[kk][i] = sa0[kk][i];
       if (ch < n_main) {
         if (s_ok[i]) {
-          const float *src = p.in + s_off[i] + (cc0 + ch) * 16;
-          sa0[i] = *reinterpret_cast<const f32x4 *>(src);
-          sa1[i] = *reinterpret_cast<const f32x4 *>(src + 4);
+          const float *src = p.in + s_off[i] + (cc0 + ch * KC + kk) * 16;
+          sa0[kk][i] = *reinterpret_cast<const f32x4 *>(src);
+          sa1[kk][i] = *reinterpret_cast<const f32x4 *>(src + 4);
         }
       } else if (s_core[i]) {
-        const float *src = p.in2 + s_off2[i] + (ch - n_main) * 16;
-        sa0[i] = *reinterpret_cast<const f32x4 *>(src);
-        sa1[i] = *reinterpret_cast<const f32x4 *>(src + 4);
+        const float *src = p.in2 + s_off2[i] + ((ch - n_main) * KC + kk) * 16;
+        sa0[kk][i] = *reinterpret_cast<const f32x4 *>(src);
+        sa1[kk][i] = *reinterpret_cast<const f32x4 *>(src + 4);
       }
     }
   };
   auto write_strip = [&]() __attribute__((always_inline)) {
 #pragma unroll
+    for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
     for (int i = 0; i < AP; ++i)
       if (s_in[i]) {
         bf16x8 p1, p2, p3;
-        split8(sa0[i], sa1[i], p1, p2, p3);
-        *reinterpret_cast<bf16x8 *>(As + s_lds[i]) = p1;
-        *reinterpret_cast<bf16x8 *>(As + PLANE_A + s_lds[i]) = p2;
-        *reinterpret_cast<bf16x8 *>(As + 2 * PLANE_A + s_lds[i]) = p3;
+        split8(sa0[kk][i], sa1[kk][i], p1, p2, p3);
+        __bf16 *A = As + kk * 3 * PLANE_A;
+        *reinterpret_cast<bf16x8 *>(A + s_lds[i]) = p1;
+        *reinterpret_cast<bf16x8 *>(A + PLANE_A + s_lds[i]) = p2;
+        *reinterpret_cast<bf16x8 *>(A + 2 * PLANE_A + s_lds[i]) = p3;
       }
   };
   auto load_b = [&](int ch, int t) __attribute__((always_inline)) {
     if (b_thread) {
-      const __bf16 *wt = ch < n_main ? wbase + (size_t)(t * CC + cc0 + ch) * 3 * w_plane
-                                     : wbase2 + (size_t)(ch - n_main) * 3 * w_plane;
+      const __bf16 *wt = ch < n_main ? wbase + (size_t)(t * CC + cc0 + ch * KC) * 3 * w_plane
+                                     : wbase2 + (size_t)(ch - n_main) * KC * 3 * w_plane;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) rb[pl] = *reinterpret_cast<const u32x4 *>(wt + pl * w_plane);
+      for (int kk = 0; kk < KC; ++kk)                              // consecutive chunks of one tap are 3 planes apart
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rb[kk][pl] = *reinterpret_cast<const u32x4 *>(wt + (kk * 3 + pl) * w_plane);
     }
   };
   auto write_b = [&](int stage) __attribute__((always_inline)) {
     if (b_thread) {
-      __bf16 *B = Bs + stage * STAGE_B;
+      __bf16 *B = Bs + stage * KC * STAGE_B;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(B + pl * PLANE_B + tid * 8) = rb[pl];
+      for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(B + (kk * 3 + pl) * PLANE_B + tid * 8) = rb[kk][pl];
     }
   };
 
   // ---- prologue: strip of chunk 0, weights of step 0, the zero row
   load_strip(0);
   load_b(0, 0);
-  if (tid < 96) *reinterpret_cast<u32x4 *>(As + (tid >> 5) * PLANE_A + RZ * 16 + (tid & 31) * 8) = u32x4{0u, 0u, 0u, 0u};
+  if (tid < 96 * KC) *reinterpret_cast<u32x4 *>(As + (tid >> 5) * PLANE_A + RZ * 16 + (tid & 31) * 8) = u32x4{0u, 0u, 0u, 0u};
   write_strip();
   write_b(0);
   __syncthreads();
@@ -183,35 +194,39 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
         const int lrow = ((a_mask[mi] >> tt) & 1u) ? srow : RZ + (srow & 15);
         a_e[mi] = lrow * 16 + ((half ^ ((srow >> 3) & 1)) << 3);
       }
-      const __bf16 *B = Bs + (step & 1) * STAGE_B;
-      bf16x8 fb[NI][3];
-      const u32x4 fake = {(unsigned)lane * 0x01010101u + (unsigned)a_e[0], 0x3f803f80u, (unsigned)step, 0x3c003c00u};   // ABL == 4 only
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+      for (int kk = 0; kk < KC; ++kk) {
+        const __bf16 *A = As + kk * 3 * PLANE_A;
+        const __bf16 *B = Bs + ((step & 1) * KC + kk) * STAGE_B;
+        bf16x8 fb[NI][3];
+        const u32x4 fake = {(unsigned)lane * 0x01010101u + (unsigned)a_e[0], 0x3f803f80u, (unsigned)step, 0x3c003c00u};   // ABL == 4 only
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          fb[ni][pl] = (ABL == 4) ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        bf16x8 fa[3];
+          for (int pl = 0; pl < 3; ++pl)
+            fb[ni][pl] = (ABL == 4) ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          fa[pl] = (ABL == 4) ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(As + pl * PLANE_A + a_e[mi]);
+        for (int mi = 0; mi < MI; ++mi) {
+          bf16x8 fa[3];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          // smallest terms first so their sum is formed before it meets the large partial sums
-          f32x16 c = acc[mi][ni];
-          if (ABL == 3) {              // keep the fragments live, skip the matrix work
-            asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fb[ni][0]), "v"(fb[ni][1]), "v"(fb[ni][2]));
-            continue;
+          for (int pl = 0; pl < 3; ++pl)
+            fa[pl] = (ABL == 4) ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(A + pl * PLANE_A + a_e[mi]);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            // smallest terms first so their sum is formed before it meets the large partial sums
+            f32x16 c = acc[mi][ni];
+            if (ABL == 3) {              // keep the fragments live, skip the matrix work
+              asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fb[ni][0]), "v"(fb[ni][1]), "v"(fb[ni][2]));
+              continue;
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ni][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][0], c, 0, 0, 0);
+            acc[mi][ni] = c;
           }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ni][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][0], c, 0, 0, 0);
-          acc[mi][ni] = c;
         }
       }
     }
@@ -234,13 +249,13 @@ __global__ __launch_bounds__(256, 3) void conv_strip_bf16x6_kernel(const ConvPar
   conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
 }
 
-int launch_conv_strip(const ConvParams &p, int bm, int bn, hipStream_t s) {
-  if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || (p.cin_p >> 4) % p.splits) return DT_E_ARG;
+int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s) {
+  if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || (kc != 1 && kc != 2)) return DT_E_ARG;
+  if ((p.cin_p >> 4) % (p.splits * kc) || (p.in2 && (p.cin2_p >> 4) % kc)) return DT_E_ARG;
   if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 strip items per thread cover BM + 2(W+1) <= 256 rows
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   const int R = bm + 2 * (p.W + 1);
-  const size_t lds = ((size_t)3 * (((R + 7) & ~7) + 16) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
-  if (lds > 65536) return DT_E_SHAPE;
+  const size_t lds = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 16) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
   if (p.ablate && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
     switch (p.ablate) {
       case 1: conv_strip_bf16x6_kernel<128, 128, 1><<<grid, 256, lds, s>>>(p); break;
@@ -253,6 +268,24 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, hipStream_t s) {
     DT_LAUNCH_CHECK();
     return DT_OK;
   }
+  if (kc == 2) {
+    static bool attr_set = false;   // 128x128 needs 80 KB of dynamic LDS
+    if (!attr_set) {
+      DT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 128, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+      DT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 64, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+      DT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 128, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+      DT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 64, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+      attr_set = true;
+    }
+    if (lds > 98304) return DT_E_SHAPE;
+    if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128, 0, 2><<<grid, 256, lds, s>>>(p);
+    else if (bm == 128) conv_strip_bf16x6_kernel<128, 64, 0, 2><<<grid, 256, lds, s>>>(p);
+    else if (bn == 128) conv_strip_bf16x6_kernel<64, 128, 0, 2><<<grid, 256, lds, s>>>(p);
+    else conv_strip_bf16x6_kernel<64, 64, 0, 2><<<grid, 256, lds, s>>>(p);
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
+  if (lds > 65536) return DT_E_SHAPE;
   if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128><<<grid, 256, lds, s>>>(p);
   else if (bm == 128) conv_strip_bf16x6_kernel<128, 64><<<grid, 256, lds, s>>>(p);
   else if (bn == 128) conv_strip_bf16x6_kernel<64, 128><<<grid, 256, lds, s>>>(p);

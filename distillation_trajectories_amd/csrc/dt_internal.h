@@ -68,7 +68,8 @@ struct ConvParams {
   float *slab;
   int bm, bn;          // tile override (0 = pick by heuristic); bn = 128 needs n_p % 128 == 0
   int prec;            // 0: exact fp32 MFMA (w = fp32 pack), 1: split-bf16 (w = bf16x3 pack), 2: 1 fed by LDS-DMA,
-                       // 3: split-bf16 strip kernel (3x3 only; `splits` then divides the channel chunks, not the taps)
+                       // 3: split-bf16 strip kernel (3x3 only; `splits` then divides the channel chunks, not the taps),
+                       // 4: strip kernel with two channel chunks (K = 32) per step
   // enc1's 1x1 skip of the C<=4 channel image, recomputed in the epilogue instead of being
   // materialised: add = sum_c x3[m*x3_stride + c*x3_step] * w3[n*4+c] + w3[n*4+3]
   const float *x3;
@@ -92,7 +93,7 @@ struct ConvParams {
 int launch_conv(const ConvParams &p, hipStream_t s);
 int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s);
 int launch_conv_bf16x6_dma(const ConvParams &p, int bm, int bn, hipStream_t s);
-int launch_conv_strip(const ConvParams &p, int bm, int bn, hipStream_t s);   // prec 3: 3x3 only, split-K over channel chunks
+int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s);   // prec 3 (kc 1) / 4 (kc 2): 3x3 only
 int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int n_p,
                             int split_c, int split_cp, hipStream_t s);
 struct ConvChoice { int bm, bn, splits, prec, fuse; };

@@ -246,12 +246,14 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     }
   }
   if (c.prec == 2 && !p.in_pl) c.prec = 1;
-  if (c.prec == 3 && p.tap_hi - p.tap_lo != 9) c.prec = 1;          // the strip kernel is the full 3x3 walk only
+  if (c.prec >= 3 && p.tap_hi - p.tap_lo != 9) c.prec = 1;          // the strip kernel is the full 3x3 walk only
+  if (c.prec == 4 && (p.cin_p >> 4) % 2) c.prec = 3;                // two chunks per step need an even chunk count
   if (p.x3 || j == 0 || p.M > kSplitMaxRows) c.splits = 1;          // (enc1: no slab; its conv2 keeps the fused x3 epilogue)
-  if (c.prec == 3 ? ((p.cin_p >> 4) % c.splits != 0) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
+  if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * (c.prec == 4 ? 2 : 1)) != 0)
+                  : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
   if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
-  if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0) {
+  if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0 && !(c.prec == 4 && (k.cin_p >> 4) % 2)) {
     // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
     p.add = nullptr;
     p.in2 = in; p.w2 = c.prec >= 1 ? k.wrb : k.wr; p.bias2 = k.hr; p.cin2_p = k.cin_p; p.cin2_real = k.cin;
@@ -507,19 +509,21 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       // Kernel families worth timing (the search is paid once per model and shape, so it is pruned to what the
       // per-layer tables show can win): exact-fp32 mode -> the fp32-MFMA kernel only; otherwise the strip kernel
       // for full 3x3 walks, the plain split-bf16 kernel for everything else, the LDS-DMA kernel where twins exist.
-      for (int prec = 0; prec <= 3; ++prec) {
+      for (int prec = 0; prec <= 4; ++prec) {
         if (h->precision == DT_PREC_FP32 ? prec != 0 : prec == 0) continue;
         if (prec == 2 && !p.in_pl) continue;
-        if (prec == 3 && !full3x3) continue;
+        if (prec >= 3 && !full3x3) continue;
+        if (prec == 4 && (p.cin_p >> 4) % 2) continue;
         if (prec == 1 && full3x3) continue;
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
           // 3x3 walks split by taps 1/3/9; the strip kernel and single-tap layers by channel chunks 1/2/4/8
           const long long tiles = (long long)((p.M + bm - 1) / bm) * (p.n_p / bn);
-          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= ((prec == 3 || !walk9) ? 2 : 3))
+          for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= ((prec >= 3 || !walk9) ? 2 : 3))
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
-            if ((prec == 3 || !walk9) && (p.cin_p >> 4) % sp) continue;
+            if ((prec >= 3 || !walk9) && (p.cin_p >> 4) % (sp * (prec == 4 ? 2 : 1))) continue;
+            if (prec == 4 && fuse && (kw.cin_p >> 4) % 2) continue;
             if (sp > 1 && tiles * (sp / 2) >= 1024) continue;          // already >= 4 workgroups per CU without this split
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
@@ -622,7 +626,7 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
     return DT_OK;
   }
   if (!p.bm || !p.bn) { const ConvChoice c = heuristic_choice(p.M, p.n_p, 1); p.bm = c.bm; p.bn = c.bn; }
-  *bm = p.bm; *bn = p.bn; *splits = p.splits; *prec = p.prec + (p.in2 ? 4 : 0); *tuned = t != nullptr;
+  *bm = p.bm; *bn = p.bn; *splits = p.splits; *prec = p.prec + (p.in2 ? 8 : 0); *tuned = t != nullptr;
   if (slot == 0) {   // folded into conv2?
     ConvParams c2;
     conv_slot(h, block, 2, &dummy, &dummy, pl, batch_total, &dummy, 1, t ? &t->c[block][2] : nullptr, c2);
@@ -637,7 +641,7 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
   if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H < 16 || W < 16 || H % 16 || W % 16 || batch_total < 1)
     return DT_E_ARG;
   if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return DT_E_ARG;
-  if (splits < 1 || splits > 9 || prec < 0 || prec > 3 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
+  if (splits < 1 || splits > 9 || prec < 0 || prec > 4 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
   if (splits == 5 || splits == 6 || splits == 7) return DT_E_ARG;
   if (prec == 2 && !h->planes) return DT_E_ARG;
   if (h->blk[block].n_p % bn) return DT_E_ARG;

@@ -113,7 +113,8 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace_
                      void *stream);
 /* report hook: tile (bm x bn), tap split and arithmetic (0 fp32 MFMA, 1 split-bf16 split in the consumer,
  * 2 split-bf16 fed by LDS-DMA from pre-split plane tensors, 3 split-bf16 "strip" kernel that stages a
- * 3x3 layer's activation tile once per channel chunk for all nine taps; +4 when the block's 1x1 skip is folded into
+ * 3x3 layer's activation tile once per channel chunk for all nine taps, 4 the same with two channel chunks
+ * (K = 32) per step; +8 when the block's 1x1 skip is folded into
  * this conv2 launch) in use for block (0..7), slot (0 skip, 1 conv1, 2 conv2);
  * bm = 0 means the slot has no launch of its own */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
@@ -121,7 +122,7 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
 
 /* tuning / test hook: pin the launch choice of one convolution of a forward shape (the other slots keep
  * their current choice).  bm x bn in {64,128}^2;
- * prec 0..3 as reported by dt_unet_conv_choice; splits in {1,3,9} taps, or 1..8 channel-chunk groups for the
+ * prec 0..4 as reported by dt_unet_conv_choice; splits in {1,3,9} taps, or 1..8 channel-chunk groups for the
  * strip kernel (prec 3; reset to 1 where it does not divide); fuse only for slot 2. */
 int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn,
                             int splits, int prec, int fuse);
