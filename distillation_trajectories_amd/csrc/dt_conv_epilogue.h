@@ -74,9 +74,11 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
+      float vv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
+        vv[r] = 0.f;
         if (m >= p.M) continue;
         float v;
         if (p.in2) {
@@ -97,11 +99,30 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
           v += rs;
         }
         p.out[o] = v;
+        vv[r] = v;
         if (p.out_pl) {
           __bf16 *pl = reinterpret_cast<__bf16 *>(p.out_pl) + plane_index(m, n, p.cout_p >> 4);
           __bf16 a1, a2, a3;
           split3(v, a1, a2, a3);
           pl[0] = a1; pl[16] = a2; pl[32] = a3;
+        }
+      }
+      if (p.pool_out) {
+        // Register r holds tile row (r&3) + 8*(r>>2) + 4*half.  A 32-row tile starts on an even picture row, so for
+        // W = 16 the window of even column c is registers {r, r+1, r+8, r+9}, for W = 8 it is {r, r+1, r+4, r+5}.
+        const int HW = p.H * p.W, Wo = p.W >> 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r16 = (q & 1) * 2 + (q >> 1) * 4, r8 = (q & 1) * 2 + (q >> 1) * 8;
+          const int r = p.W == 16 ? r16 : r8;
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m >= p.M) continue;
+          const float mx = p.W == 16 ? fmaxf(fmaxf(vv[r16], vv[r16 + 1]), fmaxf(vv[r16 + 8], vv[r16 + 9]))
+                                     : fmaxf(fmaxf(vv[r8], vv[r8 + 1]), fmaxf(vv[r8 + 4], vv[r8 + 5]));
+          const int b = m / HW, rem = m - b * HW;
+          const int y = rem / p.W, x = rem - y * p.W;
+          const size_t mo = ((size_t)b * (p.H >> 1) + (y >> 1)) * Wo + (x >> 1);
+          p.pool_out[mo * p.cout_p + n] = mx;
         }
       }
     }

@@ -87,6 +87,9 @@ struct ConvParams {
   // inputs of the LDS-DMA kernel (prec == 2) and, when out_pl is set, an extra output of the epilogue
   const void *in_pl, *in2_pl, *zero;
   void *out_pl;
+  // fused 2x2 max pool of the output (encoder conv2, unsplit launches, W in {8, 16}: every pooling window then lies in
+  // one lane's accumulator registers): also written, [M/4][cout_p]; nullptr = the separate maxpool_kernel runs
+  float *pool_out;
   int ablate;          // timing experiments only (wrong results): 1 no barrier, 2 no LDS reads, 3 no MFMA, 4 no staging
 };
 

@@ -252,6 +252,8 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * (c.prec == 4 ? 2 : 1)) != 0)
                   : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
+  // encoder blocks enc1..enc4 feed a 2x2 max pool: folded into this launch's epilogue where the windows are in-lane
+  if (slot == 2 && j <= 3 && c.splits == 1 && !u->planes && (w == 8 || w == 16) && h % 2 == 0) p.pool_out = ws + pl.pool[j];
   if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
   if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0 && !(c.prec == 4 && (k.cin_p >> 4) % 2)) {
     // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
@@ -292,7 +294,10 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
   if (st) return st;
   const float *cur = ws + pl.a0;
   for (int j = 0; j < kBlocks; ++j) {
-    if (j >= 1 && j <= 4) {        // encoder: pool the previous block's output
+    if (j >= 1 && j <= 4) {        // encoder: pool the previous block's output (unless its conv2 already did)
+      ConvParams prev;
+      conv_slot(u, j - 1, 2, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j - 1][2] : nullptr, prev);
+      if (!prev.pool_out)
       st = launch_maxpool(ws + pl.o[j - 1], ws + pl.pool[j - 1], u->planes ? ws + pl.pool_pl[j - 1] : nullptr, Bt,
                           pl.H[j - 1], pl.W[j - 1], u->blk[j - 1].cout_p, s);
       if (st) return st;
