@@ -19,6 +19,8 @@
 //
 // Split-K runs over channel chunks (grid.z slabs, summed in z order by splitk_epilogue_kernel); the block's
 // fused 1x1 skip walk follows as single-tap chunks over in2 / w2, as in the plain kernel.
+#include <type_traits>
+
 #include "dt_conv_epilogue.h"
 
 namespace dt {
@@ -145,10 +147,18 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
         *reinterpret_cast<bf16x8 *>(A + 2 * PLANE_A + s_lds[i]) = p3;
       }
   };
-  auto load_b = [&](int ch, int t) __attribute__((always_inline)) {
+  // The weight tiles are visited in a fixed order, so a running pointer replaces per-step index arithmetic:
+  // next tap of the chunk group (+tap_stride), first tap of the next group, the skip weights, next skip group.
+  const size_t tap_stride = (size_t)CC * 3 * w_plane, group_stride = (size_t)KC * 3 * w_plane;
+  const __bf16 *wrun = wbase + (size_t)cc0 * 3 * w_plane;
+  enum { ADV_NONE = 0, ADV_TAP, ADV_GROUP, ADV_SKIP0, ADV_SKIP };
+  auto load_b = [&](int adv) __attribute__((always_inline)) {
+    if (adv == ADV_TAP) wrun += tap_stride;
+    else if (adv == ADV_GROUP) wrun = wrun - 8 * tap_stride + group_stride;
+    else if (adv == ADV_SKIP0) wrun = wbase2;
+    else if (adv == ADV_SKIP) wrun += group_stride;
     if (b_thread) {
-      const __bf16 *wt = ch < n_main ? wbase + (size_t)(t * CC + cc0 + ch * KC) * 3 * w_plane
-                                     : wbase2 + (size_t)(ch - n_main) * KC * 3 * w_plane;
+      const __bf16 *wt = wrun;
 #pragma unroll
       for (int kk = 0; kk < KC; ++kk)                              // consecutive chunks of one tap are 3 planes apart
 #pragma unroll
@@ -167,30 +177,33 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
 
   // ---- prologue: strip of chunk 0, weights of step 0, the zero row
   load_strip(0);
-  load_b(0, 0);
+  load_b(ADV_NONE);
   if (tid < 96 * KC) *reinterpret_cast<u32x4 *>(As + (tid >> 5) * PLANE_A + RZ * 16 + (tid & 31) * 8) = u32x4{0u, 0u, 0u, 0u};
   write_strip();
   write_b(0);
   __syncthreads();
 
-  int ch = 0, t = 0, step = 0;
-  while (true) {
-    const int ntaps = ch < n_main ? 9 : 1;
-    const bool last_tap = t == ntaps - 1;
-    const bool next_chunk = ch + 1 < n_chunks;
+  // One step = one tap of one (KC-chunk) group.  TT is the tap as a compile-time constant: the nine taps of a main
+  // chunk are unrolled, so shifts, mask bits and the whole walk bookkeeping fold away and only the chunk loop is
+  // left as scalar control.
+  int step = 0;
+  auto do_step = [&](auto TT, int ch, bool first_tap, bool last_tap, bool next_chunk, int adv) __attribute__((always_inline)) {
+    constexpr int tt = decltype(TT)::value;
     const bool more = !last_tap || next_chunk;
-    if (t == 0 && next_chunk && ABL != 5) load_strip(ch + 1);     // lands while this chunk's taps run
-    if (more && ABL != 2) load_b(last_tap ? ch + 1 : ch, last_tap ? 0 : t + 1);
-
+    if (first_tap && next_chunk && ABL != 5) load_strip(ch + 1);   // lands while this chunk's taps run
+    if (more && ABL != 2) load_b(adv);
     {
-      const int tt = ch < n_main ? t : 4;                          // the skip walk is a centre tap
-      const int shift = (tt / 3 - 1) * p.W + (tt % 3 - 1);
+      int wv = p.W;
+      asm volatile("" : "+s"(wv));           // likewise: do not keep nine precomputed shifts in SGPRs
+      const int shift = (tt / 3 - 1) * wv + (tt % 3 - 1);
       int a_e[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         // an out-of-picture tap reads zero row RZ + (srow & 15) at the same physical half: the bank a lane hits is
         // the one its in-picture read would hit, so any mix of the two stays conflict-free
-        const int srow = a_row[mi] + shift;
+        int row0 = a_row[mi];
+        asm volatile("" : "+v"(row0));       // keeps the nine taps' addresses from being hoisted out of the chunk loop (18+ VGPRs)
+        const int srow = row0 + shift;
         const int lrow = ((a_mask[mi] >> tt) & 1u) ? srow : RZ + (srow & 15);
         a_e[mi] = lrow * 16 + ((half ^ ((srow >> 3) & 1)) << 3);
       }
@@ -230,7 +243,6 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
         }
       }
     }
-
     if (more && ABL != 2) write_b((step + 1) & 1);
     if (last_tap && next_chunk && ABL != 5) {
       __syncthreads();                                             // every wave is done with this chunk's strip
@@ -238,14 +250,23 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     }
     if (ABL != 1 || last_tap) __syncthreads();
     ++step;
-    if (last_tap) {
-      if (ch + 1 == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
-      if (!next_chunk) break;
-      ++ch; t = 0;
-    } else {
-      ++t;
-    }
+  };
+
+  for (int ch = 0; ch < n_main; ++ch) {                            // 3x3 walk: nine unrolled taps per chunk group
+    const bool next_chunk = ch + 1 < n_chunks;
+    do_step(std::integral_constant<int, 0>{}, ch, true, false, next_chunk, ADV_TAP);
+    do_step(std::integral_constant<int, 1>{}, ch, false, false, next_chunk, ADV_TAP);
+    do_step(std::integral_constant<int, 2>{}, ch, false, false, next_chunk, ADV_TAP);
+    do_step(std::integral_constant<int, 3>{}, ch, false, false, next_chunk, ADV_TAP);
+    do_step(std::integral_constant<int, 4>{}, ch, false, false, next_chunk, ADV_TAP);
+    do_step(std::integral_constant<int, 5>{}, ch, false, false, next_chunk, ADV_TAP);
+    do_step(std::integral_constant<int, 6>{}, ch, false, false, next_chunk, ADV_TAP);
+    do_step(std::integral_constant<int, 7>{}, ch, false, false, next_chunk, ADV_TAP);
+    do_step(std::integral_constant<int, 8>{}, ch, false, true, next_chunk, ch + 1 < n_main ? ADV_GROUP : ADV_SKIP0);
+    if (ch + 1 == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
   }
+  for (int ch = n_main; ch < n_chunks; ++ch)                       // fused 1x1 skip walk: centre tap only
+    do_step(std::integral_constant<int, 4>{}, ch, true, true, ch + 1 < n_chunks, ADV_SKIP);
   conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
 }
 

@@ -13,7 +13,7 @@ x = torch.randn(256, 3, 16, 16, device="cuda:0")
 tb = h.time_bias([10, 10], [_hip.COND_NONE, _hip.COND_ONE])
 h.forward(x, tb, 2, 256, tune=False)
 for (j, slot) in ((1, 2), (7, 1), (2, 1)):
-    h.set_conv_choice(512, 16, 16, j, slot, 128, 128, 1, 3, 0)
+    h.set_conv_choice(512, 16, 16, j, slot, 128, 128, 1, int(os.environ.get("DT_ONE_PREC", "4")), 0)
 for _ in range(3):
     h.forward(x, tb, 2, 256, tune=False)
 torch.cuda.synchronize()
