@@ -101,6 +101,22 @@ def test_unet_forward_odd_channel_counts(models, sf):
     assert_close(got.cpu().numpy(), want.numpy(), what=f"sf={sf}")
 
 
+@pytest.mark.parametrize("hw", [(16, 32), (32, 16), (48, 16)])
+def test_unet_forward_non_square_images(models, hw):
+    """H != W (the reference only ever uses squares, the kernels index rows and columns separately): strip rows,
+    tap masks, the in-epilogue pool (W in {8, 16}) and the low-resolution head against the oracle."""
+    import copy
+    m = models(0.5)
+    sd = m.state_dict()
+    x = seeded_noise(78, (3, 3, hw[0], hw[1]))
+    t = torch.tensor([2, 31, 49])
+    cond = torch.tensor([[1.0], [0.0], [1.0]])
+    with torch.no_grad():
+        want = unet_ref.unet_forward(sd, x, t, cond)
+    got = copy.deepcopy(m).to(DEV)(x.to(DEV), t.to(DEV), cond.to(DEV))
+    assert_close(got.cpu().numpy(), want.numpy(), what=f"H x W = {hw}")
+
+
 def test_unet_forward_large_batch_properties(gpu_models):
     """Full bench batch (2 passes x 256) through the 128-row tiles: rows are independent (bit-exact under
     a batch permutation) and the CFG batch agrees with two separate single-pass calls (those take other
