@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
 
   // ---- strip staging: item -> (strip row, k-half), 32 contiguous bytes of one pixel
   bool s_in[AP], s_ok[AP], s_core[AP];
-  int s_off[AP], s_off2[AP], s_lds[AP];
+  int s_off[AP], s_off2[AP], s_offb[AP], s_lds[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int item = tid + i * NT;
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     const int mm = s_ok[i] ? m : 0;
     s_off[i] = mm * p.cin_p + hh * 8;
     s_off2[i] = mm * p.cin2_p + hh * 8;
+    s_offb[i] = mm * p.b_stride + hh * 8;                             // two-source block input (decoder concat)
     s_lds[i] = srow * 16 + ((hh ^ ((srow >> 3) & 1)) << 3);
   }
   // ---- weight staging: the three plane tiles of one (tap, chunk) are contiguous [BN][16] bf16 runs
@@ -122,12 +123,14 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
       sa0[kk][i] = f32x4{0.f, 0.f, 0.f, 0.f}; sa1[kk][i] = sa0[kk][i];
       if (ch < n_main) {
         if (s_ok[i]) {
-          const float *src = p.in + s_off[i] + (cc0 + ch * KC + kk) * 16;
+          const int cc = cc0 + ch * KC + kk;
+          const float *src = (p.in_b && cc >= p.cc_a) ? p.in_b + s_offb[i] + (cc - p.cc_a) * 16 : p.in + s_off[i] + cc * 16;
           sa0[kk][i] = *reinterpret_cast<const f32x4 *>(src);
           sa1[kk][i] = *reinterpret_cast<const f32x4 *>(src + 4);
         }
       } else if (s_core[i]) {
-        const float *src = p.in2 + s_off2[i] + ((ch - n_main) * KC + kk) * 16;
+        const int c2 = (ch - n_main) * KC + kk;
+        const float *src = (p.in2_b && c2 >= p.cc_a) ? p.in2_b + s_offb[i] + (c2 - p.cc_a) * 16 : p.in2 + s_off2[i] + c2 * 16;
         sa0[kk][i] = *reinterpret_cast<const f32x4 *>(src);
         sa1[kk][i] = *reinterpret_cast<const f32x4 *>(src + 4);
       }

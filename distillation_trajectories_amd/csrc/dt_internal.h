@@ -90,6 +90,11 @@ struct ConvParams {
   // fused 2x2 max pool of the output (encoder conv2, unsplit launches, W in {8, 16}: every pooling window then lies in
   // one lane's accumulator registers): also written, [M/4][cout_p]; nullptr = the separate maxpool_kernel runs
   float *pool_out;
+  // decoder blocks, strip kernel only: the block input is the concat [upsampled | encoder skip]; when in_b / in2_b is
+  // set, 16-channel chunks >= cc_a of `in` / `in2` are read from that tensor (row stride b_stride floats) instead,
+  // so the concat buffer's skip half is never written
+  const float *in_b, *in2_b;
+  int cc_a, b_stride;
   int ablate;          // timing experiments only (wrong results): 1 no barrier, 2 no LDS reads, 3 no MFMA, 4 no staging
 };
 
@@ -112,6 +117,7 @@ int launch_pack_linear_rows(const float *w, const float *b, float *wp, float *bp
 
 int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, int W, int kp, hipStream_t s);
 int launch_maxpool(const float *in, float *out, void *out_pl, int Bt, int H, int W, int cp, hipStream_t s);
+// skip == nullptr: only the upsampled channels are written (the consumers read the skip half in place)
 int launch_upcat(const float *lo, const float *skip, float *out, void *out_pl, int Bt, int h, int w, int c1p, int c2p,
                  hipStream_t s);
 int launch_head(const float *lo, const float *w, const float *bias, float *lowres, float *eps, int Bt, int h, int w_,

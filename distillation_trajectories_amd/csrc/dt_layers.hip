@@ -106,10 +106,12 @@ __device__ inline void bilinear_src(int dst, int in, int out, int &i0, int &i1, 
 __global__ void upcat_kernel(const float4 *__restrict__ lo, const float4 *__restrict__ skip, float4 *__restrict__ out,
                              void *out_pl, int Bt, int h, int w, int c1q, int c2q) {
   const int H = 2 * h, W = 2 * w, cq = c1q + c2q;
-  const size_t total = (size_t)Bt * H * W * cq;
+  const int cw = skip ? cq : c1q;                 // skip == nullptr: only the upsampled channels are written
+  const size_t total = (size_t)Bt * H * W * cw;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = i % cq;
-    size_t r = i / cq;
+    const int c = i % cw;
+    size_t r = i / cw;
+    const size_t pixel = r;
     const int x = r % W; r /= W;
     const int y = r % H;
     const int b = r / H;
@@ -129,16 +131,16 @@ __global__ void upcat_kernel(const float4 *__restrict__ lo, const float4 *__rest
       o.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
       o.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
     }
-    out[i] = o;
-    if (out_pl) store_planes4(out_pl, i / cq, c * 4, cq >> 2, o);
+    out[pixel * cq + c] = o;
+    if (out_pl) store_planes4(out_pl, pixel, c * 4, cq >> 2, o);
   }
 }
 
 int launch_upcat(const float *lo, const float *skip, float *out, void *out_pl, int Bt, int h, int w, int c1p, int c2p,
                  hipStream_t s) {
-  const size_t total = (size_t)Bt * 4 * h * w * ((c1p + c2p) / 4);
+  const size_t total = (size_t)Bt * 4 * h * w * ((c1p + (skip ? c2p : 0)) / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  ProfileScope prof(KC_UPCAT, 0.0, 4.0 * Bt * h * w * (c1p + 4.0 * c2p + 4.0 * (c1p + c2p)), s);
+  ProfileScope prof(KC_UPCAT, 0.0, 4.0 * Bt * h * w * (c1p + 4.0 * c1p + (skip ? 8.0 * c2p : 0.0)), s);
   upcat_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(lo), reinterpret_cast<const float4 *>(skip),
                                        reinterpret_cast<float4 *>(out), out_pl, Bt, h, w, c1p / 4, c2p / 4);
   DT_LAUNCH_CHECK();

@@ -264,6 +264,18 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   return true;
 }
 
+// Decoder block j reads the concat [upsampled | skip].  When both of its readers are strip launches (conv1, and the
+// 1x1 skip conv folded into conv2), they fetch the skip half straight from the encoder's output and the concat
+// buffer only ever holds the upsampled half.
+bool concat_in_place(const dt_unet *u, int j, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
+                     const TunedShape *tuned) {
+  if (j < 5 || u->planes || !u->blk[j].has_res) return false;
+  ConvParams c1, c2;
+  if (!conv_slot(u, j, 1, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][1] : nullptr, c1)) return false;
+  if (!conv_slot(u, j, 2, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][2] : nullptr, c2)) return false;
+  return c1.prec >= 3 && c1.prec <= 4 && c2.prec >= 3 && c2.prec <= 4 && c2.in2 != nullptr;
+}
+
 int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
               const TunedShape *tuned, hipStream_t s) {
   ConvParams p;
@@ -273,9 +285,17 @@ int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &p
     conv_slot(u, j, 2, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][2] : nullptr, c2);
     fused_skip = c2.in2 != nullptr;
   }
+  const bool in_place = concat_in_place(u, j, ws, pl, Bt, tb, tb_div, tuned);
   for (int slot = 0; slot < 3; ++slot) {
     if (slot == 0 && fused_skip) continue;
     if (!conv_slot(u, j, slot, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][slot] : nullptr, p)) continue;
+    if (in_place) {
+      const int skip = 8 - j;            // dec3<-enc4(3), dec2<-enc3(2), dec1<-enc2(1)
+      p.cc_a = u->blk[j].split_cp >> 4;
+      p.b_stride = u->blk[skip].cout_p;
+      if (slot == 1) p.in_b = ws + pl.o[skip];
+      if (slot == 2) p.in2_b = ws + pl.o[skip];
+    }
     const int st = launch_conv(p, s);
     if (st) return st;
   }
@@ -304,7 +324,8 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
       cur = ws + pl.pool[j - 1];
     } else if (j >= 5) {           // decoder: upsample previous output, concat the matching encoder output
       const int skip = 8 - j;      // dec3<-enc4(3), dec2<-enc3(2), dec1<-enc2(1)
-      st = launch_upcat(ws + pl.o[j - 1], ws + pl.o[skip], ws + pl.cat[j - 5], u->planes ? ws + pl.cat_pl[j - 5] : nullptr,
+      const bool in_place = concat_in_place(u, j, ws, pl, Bt, tb, tb_div, tuned);
+      st = launch_upcat(ws + pl.o[j - 1], in_place ? nullptr : ws + pl.o[skip], ws + pl.cat[j - 5], u->planes ? ws + pl.cat_pl[j - 5] : nullptr,
                         Bt, pl.H[j - 1], pl.W[j - 1], u->blk[j - 1].cout_p, u->blk[skip].cout_p, s);
       if (st) return st;
       cur = ws + pl.cat[j - 5];
