@@ -150,27 +150,40 @@ int launch_upcat(const float *lo, const float *skip, float *out, void *out_pl, i
 // Head (models.py:221-224): eps = conv1x1(bilinear_x2(d)) + bias.  Both maps are linear and the bilinear
 // weights sum to one, so eps = bilinear_x2(conv1x1(d) + bias): the 1x1 conv runs at the LOW resolution
 // (4x fewer dot products, one NHWC pixel per wave) and only C channels are upsampled.
-// Kernel 1: one wave per low-res pixel; lanes stride the channel axis (coalesced), the C partial dot
-// products are reduced with __shfl_down over the 64-lane wavefront.  lowres[b][y][x][4].
+// Kernel 1: eight lanes per low-res pixel (eight pixels per wave); a lane walks float4 number l, l+8, ... of the
+// pixel's channel row (128 contiguous bytes per group and step), the C partial dot products are reduced with three
+// xor-shuffles inside the group.  lowres[b][y][x][4].
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ lo, const float *__restrict__ wf,
                                                    const float *__restrict__ bias, float *__restrict__ lowres,
                                                    size_t n_pix, int cp, int C, int c_real) {
-  const int lane = threadIdx.x & 63;
-  const size_t wave0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
-  const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-  for (size_t pix = wave0; pix < n_pix; pix += n_waves) {
-    const float *p = lo + pix * cp;
+  const int sub = threadIdx.x & 7;
+  const size_t g0 = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3;
+  const size_t n_groups = ((size_t)gridDim.x * blockDim.x) >> 3;
+  const int c4 = cp >> 2;
+  for (size_t base = g0 - (g0 & 7); base < n_pix; base += n_groups) {     // a wave's eight groups advance together
+    const size_t pix = base + (g0 & 7);
     float part[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane; k < c_real; k += 64) {
-      const float v = p[k];
+    if (pix < n_pix) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(lo + pix * cp);
+      for (int q = sub; q < c4; q += 8) {
+        const float4 v = p4[q];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < C) part[c] = fmaf(wf[c * c_real + k], v, part[c]);
+        for (int e = 0; e < 4; ++e) {
+          const int k = q * 4 + e;
+          if (k < c_real) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < C) part[c] = fmaf(wf[c * c_real + k], vv[e], part[c]);
+          }
+        }
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      for (int off = 32; off > 0; off >>= 1) part[c] += __shfl_down(part[c], off, 64);
-    if (lane == 0) {
+#pragma unroll
+      for (int off = 4; off > 0; off >>= 1) part[c] += __shfl_xor(part[c], off, 64);
+    if (sub == 0 && pix < n_pix) {
       float4 o = make_float4(part[0] + bias[0], 0.f, 0.f, 0.f);
       if (C > 1) o.y = part[1] + bias[1];
       if (C > 2) o.z = part[2] + bias[2];
@@ -206,7 +219,7 @@ int launch_head(const float *lo, const float *wf, const float *bias, float *lowr
   if (C > 3) return DT_E_SHAPE;
   const size_t n_pix = (size_t)Bt * h * w;
   {
-    const size_t blocks = (n_pix + 3) / 4;
+    const size_t blocks = (n_pix + 31) / 32;             // 8 lanes per pixel
     ProfileScope prof(KC_HEAD, 2.0 * n_pix * C * c_real, 4.0 * n_pix * (c_real + 4.0), s);
     head_kernel<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, s>>>(lo, wf, bias, lowres, n_pix, cp, C, c_real);
     DT_LAUNCH_CHECK();
