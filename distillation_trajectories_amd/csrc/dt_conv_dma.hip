@@ -23,7 +23,7 @@ namespace dt {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 4) void conv_gemm_bf16x6_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf16x6_dma_kernel(const ConvParams p) {
   constexpr int WN = 2;
   constexpr int MI = BM / 64, NI = BN / 64;
   constexpr int PLANE_A = BM * 16, PLANE_B = BN * 16;            // bf16 elements per plane per stage
