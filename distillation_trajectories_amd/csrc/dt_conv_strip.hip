@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     }
   };
 
+  const long long tl0 = p.ablate == 8 ? wall_clock64() : 0;      // timeline diagnostic (tools/block_timeline.py)
   // ---- prologue: strip of chunk 0, weights of step 0, the zero row
   load_strip(0);
   load_b(ADV_NONE);
@@ -270,7 +271,19 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   }
   for (int ch = n_main; ch < n_chunks; ++ch)                       // fused 1x1 skip walk: centre tap only
     do_step(std::integral_constant<int, 4>{}, ch, true, true, ch + 1 < n_chunks, ADV_SKIP);
+  const long long tl1 = p.ablate == 8 ? wall_clock64() : 0;
   conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
+  if (p.ablate == 8 && p.splits == 1) {   // (start, loop end, end, hw id) per workgroup into the unused split-K slab
+    __syncthreads();
+    if (tid == 0) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      long long *rec = reinterpret_cast<long long *>(p.slab) + 4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+      rec[0] = tl0; rec[1] = tl1; rec[2] = wall_clock64(); rec[3] = ((long long)xcc << 32) | hw;
+    }
+  }
 }
 
 int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s) {
@@ -287,6 +300,7 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
       case 3: conv_strip_bf16x6_kernel<128, 128, 3><<<grid, 256, lds, s>>>(p); break;
       case 4: conv_strip_bf16x6_kernel<128, 128, 4><<<grid, 256, lds, s>>>(p); break;
       case 5: conv_strip_bf16x6_kernel<128, 128, 5><<<grid, 256, lds, s>>>(p); break;
+      case 8: conv_strip_bf16x6_kernel<128, 128, 0><<<grid, 256, lds, s>>>(p); break;
       default: return DT_E_ARG;
     }
     DT_LAUNCH_CHECK();

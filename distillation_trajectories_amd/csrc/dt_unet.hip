@@ -697,8 +697,9 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
 int dt_unet_debug_activation(const dt_unet *h, int batch_total, int H, int W, int which, size_t *off, int *cp,
                              int *oh, int *ow) {
   if (!h || !off || !cp || !oh || !ow) return DT_E_NULL;
-  if (which < 0 || which >= kBlocks || batch_total < 1 || H % 16 || W % 16) return DT_E_ARG;
+  if (which < 0 || which > kBlocks || batch_total < 1 || H % 16 || W % 16) return DT_E_ARG;
   const Plan pl = make_plan(h, batch_total, H, W);
+  if (which == kBlocks) { *off = pl.slab; *cp = 0; *oh = 0; *ow = 0; return DT_OK; }   // the split-K slab (diagnostics)
   *off = pl.o[which]; *cp = h->blk[which].cout_p; *oh = pl.H[which]; *ow = pl.W[which];
   return DT_OK;
 }
