@@ -37,3 +37,7 @@ for j, slot, name, grid in ((1, 2, "enc2.conv2", 512), (7, 1, "dec1.conv1 (s1)",
     print(f"  loop   : median {np.median(loop_end-start):6.1f}  min {np.min(loop_end-start):6.1f}  max {np.max(loop_end-start):6.1f} us")
     print(f"  epilog : median {np.median(end-loop_end):6.1f}  max {np.max(end-loop_end):6.1f} us")
     print(f"  last workgroup ends {end.max():6.1f} us after the first one started; median end {np.median(end):6.1f}", flush=True)
+    loop = loop_end - start
+    print("  loop time by XCD (median / max us):", "  ".join(f"{int(k)}: {np.median(loop[xcc == k]):.0f}/{loop[xcc == k].max():.0f}" for k in np.unique(xcc)))
+    order = np.arange(grid)
+    print("  loop time by block-id quarter (median):", "  ".join(f"{np.median(loop[(order >= a) & (order < a + grid // 4)]):.0f}" for a in range(0, grid, grid // 4)))
