@@ -88,6 +88,18 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
     const bool tb_fast = p.m_per_tb >= 32, hw_fast = HW >= 32;
     const int tq = mt / p.m_per_tb, tr = mt - tq * p.m_per_tb;
     const int iq = mt / HW, ir = mt - iq * HW;
+    // time bias: a 32-row tile sees at most two rows of the table (fast path): both are loaded once per column
+    float tb0[NI], tb1[NI];
+    const bool tb_two = p.tb && tb_fast;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      tb0[ni] = tb1[ni] = 0.f;
+      if (tb_two && ncol[ni] >= 0) {
+        const int last = (p.M - 1) / p.m_per_tb;                 // rows past M are never stored; keep the read in range
+        tb0[ni] = p.tb[(size_t)(tq < last ? tq : last) * p.tb_stride + ncol[ni]];
+        tb1[ni] = p.tb[(size_t)(tq + 1 < last ? tq + 1 : last) * p.tb_stride + ncol[ni]];
+      }
+    }
     float vv[NI][16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -98,10 +110,8 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       if (m >= p.M) continue;
       const size_t orow = (size_t)m * p.cout_p;
       const float *tbrow = nullptr;
-      if (p.tb) {
-        const int g = tb_fast ? tq + (tr + L >= p.m_per_tb ? 1 : 0) : m / p.m_per_tb;
-        tbrow = p.tb + (size_t)g * p.tb_stride;
-      }
+      const bool tb_second = tr + L >= p.m_per_tb;
+      if (p.tb && !tb_fast) tbrow = p.tb + (size_t)(m / p.m_per_tb) * p.tb_stride;
       float x0 = 0.f, x1 = 0.f, x2 = 0.f;
       if (p.x3) {
         const float *xr = p.x3 + (size_t)m * p.x3_stride;
@@ -120,7 +130,8 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
           v = acc[mi][ni][r] * sc[ni] + sh[ni];
           if (p.relu) v = fmaxf(v, 0.f);
         }
-        if (tbrow) v += tbrow[n];
+        if (tb_two) v += tb_second ? tb1[ni] : tb0[ni];
+        else if (tbrow) v += tbrow[n];
         if (p.add) v += p.add[orow + n];
         if (p.x3) {
           float rs = w3[ni].w;
