@@ -204,13 +204,17 @@ ConvChoice heuristic_choice(int M, int n_p, int taps) {
 // (all S loads of an element are issued before the first add); S = 0 walks p.splits at run time.
 template <int S>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p) {
-  const int c4 = p.cout_p >> 2;
-  const size_t total = (size_t)p.M * c4;
+  // 32-bit index math (launch_conv guarantees M * cout_p < 2^31); the row is only divided when cout_p / 4 is not a
+  // power of two, and the time-bias row by a 32-bit division per float4 instead of a 64-bit one
+  const unsigned c4 = (unsigned)p.cout_p >> 2;
+  const unsigned total = (unsigned)p.M * c4;
   const size_t slab_stride = (size_t)p.M * p.cout_p;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i % c4) * 4;
-    const size_t m = i / c4;
-    const size_t o = m * p.cout_p + n;
+  const bool pow2 = (c4 & (c4 - 1)) == 0;
+  const int sh4 = 31 - __builtin_clz(c4);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned m = pow2 ? i >> sh4 : i / c4;
+    const int n = (int)(i - m * c4) * 4;
+    const size_t o = (size_t)m * p.cout_p + n;
     float4 a;
     if (S > 0) {
       float4 part[S > 0 ? S : 1];
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p
     float4 v = make_float4(a.x * sc.x + sh.x, a.y * sc.y + sh.y, a.z * sc.z + sh.z, a.w * sc.w + sh.w);
     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (p.tb) {
-      const float4 t = *reinterpret_cast<const float4 *>(p.tb + (m / p.m_per_tb) * p.tb_stride + n);
+      const float4 t = *reinterpret_cast<const float4 *>(p.tb + (size_t)(m / (unsigned)p.m_per_tb) * p.tb_stride + n);
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     if (p.add) {
