@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     else if (adv == ADV_SKIP0) wrun = wbase2;
     else if (adv == ADV_SKIP) wrun += group_stride;
     if (b_thread) {
-      const __bf16 *wt = wrun;
+      const __bf16 *wt = ABL == 6 ? wbase : wrun;                  // ABL 6: every tile re-reads the first one (cache-hot)
 #pragma unroll
       for (int kk = 0; kk < KC; ++kk)                              // consecutive chunks of one tap are 3 planes apart
 #pragma unroll
@@ -300,6 +300,7 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
       case 3: conv_strip_bf16x6_kernel<128, 128, 3><<<grid, 256, lds, s>>>(p); break;
       case 4: conv_strip_bf16x6_kernel<128, 128, 4><<<grid, 256, lds, s>>>(p); break;
       case 5: conv_strip_bf16x6_kernel<128, 128, 5><<<grid, 256, lds, s>>>(p); break;
+      case 6: conv_strip_bf16x6_kernel<128, 128, 6><<<grid, 256, lds, s>>>(p); break;
       case 8: conv_strip_bf16x6_kernel<128, 128, 0><<<grid, 256, lds, s>>>(p); break;
       default: return DT_E_ARG;
     }

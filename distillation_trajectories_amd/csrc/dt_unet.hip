@@ -515,6 +515,13 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
   t.Bt = batch_total; t.H = H; t.W = W;
   const float *tb = h->slab;   // any readable floats: only timing matters here
   int st = DT_OK;
+  {   // The clocks of an idle GPU take tens of milliseconds of load to settle (the same launch measures 15 % slower
+      // cold): run one mid-sized layer for a while first so that the first candidates are not timed against a ramp.
+    ConvParams wp;
+    if (conv_slot(h, 1, 1, ws + pl.pool[0], ws, pl, batch_total, tb, batch_total, nullptr, wp))
+      for (int rep = 0; rep < 200 && st == DT_OK; ++rep) st = launch_conv(wp, s);
+    if (hipStreamSynchronize(s) != hipSuccess) st = (int)hipGetLastError();
+  }
   for (int j = 0; j < kBlocks && st == DT_OK; ++j) {
     const float *in = j == 0 ? ws + pl.a0 : (j <= 4 ? ws + pl.pool[j - 1] : ws + pl.cat[j - 5]);
     float skip_ms = 0.f;

@@ -18,8 +18,8 @@ lib = _hip.load()
 layers = [(0, 2, "enc1.conv2"), (1, 2, "enc2.conv2"), (7, 1, "dec1.conv1"), (2, 1, "enc3.conv1")]
 PREC = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # 1: plain split-bf16 kernel, 3: strip kernel
 NAMES = {1: ((0, "full"), (1, "no barrier"), (2, "no LDS fragment reads"), (3, "no MFMA"), (4, "no global loads"), (5, "no split VALU")),
-         3: ((0, "full"), (1, "no per-tap barrier"), (2, "no weight staging"), (3, "no MFMA"), (4, "no fragment reads"), (5, "no strip re-staging"))}
-for ab, name in NAMES[PREC]:
+         3: ((0, "full"), (1, "no per-tap barrier"), (2, "no weight staging"), (3, "no MFMA"), (4, "no fragment reads"), (5, "no strip re-staging"), (6, "cache-hot weight loads"))}
+for ab, name in ((0, "(warm-up pass)"),) + NAMES[PREC] + ((0, "full again"),):
     os.environ["DT_ABLATE"] = str(ab)
     row = f"{name:28s}"
     for j, slot, lname in layers:
