@@ -318,7 +318,8 @@ def main():
                            "peak_basis": ("dense bf16 MFMA 2500 TF/s / 6 plane products per fp32-accurate product; "
                                           f"issued bf16 MFMA rate {achieved * PLANE_PRODUCTS:.0f} TF/s; native fp32 MFMA "
                                           f"peak is {PEAK_FP32_MFMA_TFLOPS} TF/s") if split else "dense fp32 MFMA",
-                           "traffic": traffic, "launches": dom["launches"],
+                           "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+                           "launches": dom["launches"],
                            "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                            "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
                            "instantiations": {n: {"launches": k["launches"], "avg_launch_us": round(k["ms"] / k["launches"] * 1e3, 2),
