@@ -117,6 +117,28 @@ def test_unet_forward_non_square_images(models, hw):
     assert_close(got.cpu().numpy(), want.numpy(), what=f"H x W = {hw}")
 
 
+def test_unet_forward_random_shapes():
+    """Seeded random (size factor, batch, H, W, t, cond) draws against the oracle (tools/fuzz_forward.py runs more)."""
+    import numpy as np
+    from distillation_trajectories_amd.config import Config
+    from distillation_trajectories_amd.models import DiffusionUNet
+    from distillation_trajectories_amd.synthetic import make_model
+    rng = np.random.default_rng(5)
+    for case in range(8):
+        sf = float(rng.choice([0.05, 0.2, 0.3, 0.5, 0.75, 1.0]))
+        H, W = int(rng.choice([16, 32, 48])), int(rng.choice([16, 32, 48]))
+        B = int(rng.integers(1, 24)) if H * W <= 1024 else int(rng.integers(1, 8))
+        cfg = Config(); cfg.image_size = H
+        torch.manual_seed(2000 + case)
+        m = make_model(DiffusionUNet, cfg, sf)
+        x, t = torch.randn(B, 3, H, W), torch.randint(0, 50, (B,))
+        cond = (torch.rand(B, 1) > 0.5).float()
+        with torch.no_grad():
+            want = unet_ref.unet_forward(m.state_dict(), x, t, cond)
+        got = m.to(DEV)(x.to(DEV), t.to(DEV), cond.to(DEV))
+        assert_close(got.cpu().numpy(), want.numpy(), what=f"case {case}: sf={sf} B={B} {H}x{W}")
+
+
 def test_unet_forward_large_batch_properties(gpu_models):
     """Full bench batch (2 passes x 256) through the 128-row tiles: rows are independent (bit-exact under
     a batch permutation) and the CFG batch agrees with two separate single-pass calls (those take other
