@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X: trajectory-timesteps/sec (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): teacher (size_factor 1.0) vs student (size_factor 0.5), 16x16x3,
+Default workload (BASELINE.json configs[1]): teacher (size_factor 1.0) vs student (size_factor 0.5), 16x16x3,
 T=50, batch 256, guidance scale 1.0 through the CFG sampler of utils/diffusion.py (p_sample_loop: two
 U-Net passes per step, cond=ones and cond=None, then the DDPM update), followed by the trajectory
 metrics of the 256 (teacher, student) pairs.  One "step" of this benchmark is one such pass:
-2 models x 256 samples x 50 timesteps = 25,600 trajectory-timesteps per GPU.
+2 models x 256 samples x 50 timesteps = 25,600 trajectory-timesteps per GPU.  The time/condition embedding
+tower of every (timestep, cond) row is evaluated inside the step, like every reference forward does.
+
+``--config 4`` runs the same pass at configs[4]'s shape (32x32x3, T=1000, batch 128, CFG 7, teacher + a second
+size-factor-1.0 model); ``--config 2`` runs configs[2] (11 size factors x CFG {1,3,7,20} x 64 samples per GPU
+through the grid driver, teacher once per CFG plan).
 
 Inputs (start noise x_T and the per-step Gaussian noise, shared by teacher and student) are synthetic,
-seeded, and resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), samples
-sharded across ranks, no data-path collective; the only exchange is one RCCL all-gather of the
-per-sample metric tensor at the end of each step (weak scaling: 256 samples per GPU).
+seeded, and resident in HBM before the timed region.
+
+``--gpus N`` (N > 1) without a launcher: this process spawns N rank processes (one per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in their environment) BEFORE touching the GPU, relays rank 0's JSON line and exits with the
+ranks' status.  Under ``torch.distributed.run`` (WORLD_SIZE already set) it is one of the ranks.  Samples are
+sharded across ranks, no data-path collective; the only exchange is one RCCL all-gather of the per-sample metric
+tensor at the end of each step (weak scaling: the same batch per GPU).  ``DT_BENCH_BACKEND=gloo`` lets N ranks
+share fewer GPUs to rehearse that path (tools/rehearse_ranks.sh).
 
 Prints ONE JSON line on rank 0 (contract in the task description), with a ``roofline`` object for the
-dominant kernel (HIP-event timed inside this process) and a ``cpu_baseline`` object (the oracle's
-restatement of the same loop timed on the host cores, rank 0, N=1 only).
+dominant kernel (HIP-event timed inside this process), a ``cpu_baseline`` object (the oracle's restatement of the
+same loop timed on the host cores, rank 0, N=1 only) and ``metric_delta_vs_cpu`` (GPU metrics of the first pairs
+against the oracle's full-length run on the same inputs).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -27,17 +40,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
-
 # /opt/skills/guides/MI355X_MICROARCH.md: dense matrix peaks.  The split-bf16 kernels evaluate every fp32
 # product as 6 bf16 plane products, so their fp32-equivalent ceiling is the dense bf16 peak / 6.
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PLANE_PRODUCTS = 6
-T, BATCH, H, C = 50, 256, 16, 3
-TEACHER_SF, STUDENT_SF = 1.0, 0.5
-GUIDANCE = 1.0
+C = 3
+SIZES = [0.01, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]          # configs[2] size sweep (README.md:23)
+CONFIGS = {
+    1: dict(name="configs[1]", H=16, T=50, batch=256, guidance=1.0, sf=(1.0, 0.5), seeds=(None, None)),
+    4: dict(name="configs[4]", H=32, T=1000, batch=128, guidance=7.0, sf=(1.0, 1.0), seeds=(None, 4242)),
+    2: dict(name="configs[2]", H=16, T=50, batch=64, scales=[1.0, 3.0, 7.0, 20.0], sizes=SIZES),
+}
 
 
 def parse():
@@ -45,77 +59,151 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[] index")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
-    ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (default: the configs[1] batch)")
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU (default: the config's batch)")
     ap.add_argument("--serial", action="store_true", help="run the teacher and student loops back to back on one stream")
     return ap.parse_args()
 
 
-class Workload:
-    """Device-resident state of one rank's share of the benchmark."""
+# ------------------------------------------------------------------------------------------- rank launcher
+def launch_ranks(args):
+    """Parent of a ``--gpus N`` run: N children of this script, one per GPU.  Nothing here (or imported so far)
+    initialises HIP -- the parent never touches the GPU and never execs."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()))
+    reader.start()
+    code = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and code == 0:
+                code = rc
+                sys.stderr.write(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks\n")
+                for q in pending:
+                    procs[q].terminate()          # exactly the PIDs started above
+        time.sleep(0.05)
+    reader.join()
+    lines = [ln for ln in out0 if ln.strip().startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1])
+        sys.stdout.flush()
+    elif code == 0:
+        code = 1
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+    return code
 
-    def __init__(self, device, rank, batch, concurrent=True):
+
+# ------------------------------------------------------------------------------------------- workloads
+class PairWorkload:
+    """Device-resident state of one rank's share of a (teacher, student) p_sample_loop + metrics pass."""
+
+    def __init__(self, spec, device, rank, batch, concurrent=True):
+        import torch
         from distillation_trajectories_amd import engine
-        from distillation_trajectories_amd._hip import COND_NONE, COND_ONE
         from distillation_trajectories_amd.config import Config
         from distillation_trajectories_amd.models import DiffusionUNet
         from distillation_trajectories_amd.synthetic import make_model
         from distillation_trajectories_amd.utils.diffusion import (get_diffusion_params, psample_coefficients,
                                                                    timestep_indices)
-        self.engine, self.device, self.B = engine, device, batch
+        self.torch, self.engine, self.device, self.B, self.spec = torch, engine, device, batch, spec
+        H, T = spec["H"], spec["T"]
+        self.H, self.T, self.E = H, T, C * H * H
         cfg = Config()
         cfg.image_size, cfg.timesteps, cfg.sample_steps = H, T, T
-        self.models = [make_model(DiffusionUNet, cfg, sf).to(device) for sf in (TEACHER_SF, STUDENT_SF)]
+        self.models = [make_model(DiffusionUNet, cfg, sf, seed=sd).to(device) for sf, sd in zip(spec["sf"], spec["seeds"])]
         self.handles = [engine.UNetHandle.for_module(m) for m in self.models]
         # Samples are independent, so a model's batch may run as several contiguous sub-batches, each with its own
-        # handle (workspace), HIP stream and host thread: DT_BENCH_PARTS="teacher_parts,student_parts".  Measured
-        # 1,1: 259-262 k  2,1: 270-274 k  2,2: 242 k  3,1: 225 k trajectory-timesteps/s.  The default stays 1,1:
-        # the teacher as two halves buys 4 % of wall time by overlap but halves every teacher launch, so the
-        # per-launch (roofline) figures then describe smaller, less efficient launches (all convs 126 vs 145 TF/s).
-        parts = [int(v) for v in os.environ.get("DT_BENCH_PARTS", "1,1").split(",")]   # --serial: same sub-batches, one stream
+        # handle (workspace), HIP stream and host thread: DT_BENCH_PARTS="teacher_parts,student_parts".  The default
+        # stays 1,1: the teacher as two halves buys a few % of wall time by overlap but halves every teacher launch,
+        # so the per-launch (roofline) figures then describe smaller, less efficient launches.
+        parts = [int(v) for v in os.environ.get("DT_BENCH_PARTS", "1,1").split(",")]
         self.parts = []
         for i, n in enumerate(parts):
             n = max(1, min(n, batch))
             bounds = [(batch * k // n, batch * (k + 1) // n) for k in range(n)]
             hs = [self.handles[i]] + [engine.UNetHandle(self.models[i].state_dict(), device) for _ in range(n - 1)]
             self.parts.append(list(zip(hs, bounds)))
-        self.E = C * H * H
         idx = timestep_indices(T, T)
         self.coef = psample_coefficients(get_diffusion_params(T, cfg), idx)
         self.has_noise = [i > 0 for i in idx]
         g = torch.Generator().manual_seed(1234 + rank)          # torch CPU generator, like the reference's CPU mode
         x_T = torch.randn(batch, self.E, generator=g)
-        z = torch.randn(sum(self.has_noise) * batch, self.E, generator=g)
+        n_z = sum(self.has_noise)
+        z = torch.empty(n_z * batch, self.E)
+        for s in range(n_z):                                     # slab by slab: bounded host memory at T=1000
+            z[s * batch:(s + 1) * batch] = torch.randn(batch, self.E, generator=g)
+        keep = min(2, batch)                                     # host copies of the first pairs' inputs (CPU legs)
+        self.host_inputs = (x_T[:keep].clone(), z.reshape(n_z, batch, self.E)[:, :keep].clone(), idx)
         self.x_T, self.z = x_T.to(device), z.to(device)
+        del z
         self.z_shift, k = [], 0
         for flag in self.has_noise:
             self.z_shift.append(k * batch)
             k += int(flag)
-        self.tb = [h.time_bias([i for i in idx for _ in (0, 1)], [COND_NONE, COND_ONE] * T) for h in self.handles]
+        # (t, cond) rows of the loop: pass 0 = cond None, pass 1 = cond ones (utils/diffusion.py:122-123); the
+        # embedding tower itself runs inside step()
+        self.tb_t = torch.tensor([i for i in idx for _ in (0, 1)], dtype=torch.int32).to(device)
+        self.tb_cond = torch.tensor([0.0, 1.0] * T, dtype=torch.float32).to(device)
+        self.tb_present = torch.tensor([0, 1] * T, dtype=torch.uint8).to(device)
         self.traj = [torch.empty(T + 1, batch, self.E, device=device) for _ in self.handles]
         self.part_traj = [[self.traj[i] if len(ps) == 1 else torch.empty(T + 1, hi - lo, self.E, device=device)
                            for (_, (lo, hi)) in ps] for i, ps in enumerate(self.parts)]
+        # Wasserstein sub-sampling tables when E > 1000 (trajectory_metrics.py:295-315; seed-dependent only)
+        self.w_index = self.w_rows = None
+        if self.E > 1000:
+            from distillation_trajectories_amd.analysis.metrics.trajectory_metrics import wasserstein_index_tables
+            tables, rows = wasserstein_index_tables([42 + rank * batch + s for s in range(batch)], T + 1, self.E)
+            self.w_index, self.w_rows = tables.to(device), rows.to(device)
         for i, ps in enumerate(self.parts):
             for h, (lo, hi) in ps:
                 # tile / split / arithmetic autotuning happens here, one launch shape at a time on an idle GPU
-                h.forward(self.x_T[lo:hi].reshape(hi - lo, C, H, H), self.tb[i][:2].contiguous(), 2, hi - lo, tune=True)
+                tb = h.time_bias_general(self.tb_t[:2], self.tb_cond[:2], self.tb_present[:2], 2)
+                h.forward(self.x_T[lo:hi].reshape(hi - lo, C, H, H), tb, 2, hi - lo, tune=True)
         torch.cuda.synchronize()
         self.choices = None
         self.concurrent = concurrent
         self.streams = [[torch.cuda.Stream(device=device) for _ in ps] for ps in self.parts]
+        self.units_per_step = 2 * batch * T
+
+    def describe(self, world):
+        s = self.spec
+        return {"workload": f"{s['name']}: teacher sf={s['sf'][0]} vs student sf={s['sf'][1]}, {self.H}x{self.H}x{C}, "
+                            f"T={self.T}, batch {self.B}/GPU, p_sample_loop CFG (2 U-Net passes/step, w={s['guidance']}) "
+                            f"+ time/cond embedding rows + trajectory metrics of the {self.B} pairs",
+                "batch_per_gpu": self.B, "timesteps": self.T, "image": [C, self.H, self.H],
+                "guidance_scale": s["guidance"], "unet_passes_per_step": 2,
+                "parallelism": f"sample-sharded x{world}, RCCL all-gather of metrics",
+                "streams_per_gpu": {"teacher_sub_batches": len(self.parts[0]), "student_sub_batches": len(self.parts[1])}}
 
     def step(self, world, counts):
-        """One pass of the hot path: both samplers, the metric reductions, the metric all-gather."""
+        """One pass of the hot path: embedding rows, both samplers, the metric reductions, the metric all-gather."""
         from distillation_trajectories_amd._hip import RULE_PSAMPLE
         from distillation_trajectories_amd.grid import all_gather_rows
-        eng = self.engine
+        torch, eng, H, T = self.torch, self.engine, self.H, self.T
 
         def run(i, k=0):
-            (h, (lo, hi)), tb, traj = self.parts[i][k], self.tb[i], self.part_traj[i][k]
+            (h, (lo, hi)), traj = self.parts[i][k], self.part_traj[i][k]
+            tb = h.time_bias_general(self.tb_t, self.tb_cond, self.tb_present, 2 * T)     # A1, every (t, cond) row
             traj[0].copy_(self.x_T[lo:hi])
             h.sample(RULE_PSAMPLE, traj, H, H, tb, 2, self.coef, self.has_noise, z=self.z,
-                     z_shift=[v + lo for v in self.z_shift], w_scalar=GUIDANCE)
+                     z_shift=[v + lo for v in self.z_shift], w_scalar=self.spec["guidance"])
         if self.concurrent:
             # teacher and student loops are independent: one HIP stream + one host thread each (the C call
             # releases the GIL), so the small spatial levels of one model overlap the other's work
@@ -135,17 +223,15 @@ class Workload:
             for sts in self.streams:
                 for st in sts:
                     main.wait_stream(st)
-            for i, ps in enumerate(self.parts):
-                if len(ps) > 1:                      # reassemble [T+1, B, E] for the pairwise metrics
-                    torch.cat(self.part_traj[i], dim=1, out=self.traj[i])
         else:
             for i, ps in enumerate(self.parts):
                 for k in range(len(ps)):
                     run(i, k)
-                if len(ps) > 1:
-                    torch.cat(self.part_traj[i], dim=1, out=self.traj[i])
+        for i, ps in enumerate(self.parts):
+            if len(ps) > 1:                      # reassemble [T+1, B, E] for the pairwise metrics
+                torch.cat(self.part_traj[i], dim=1, out=self.traj[i])
         sums = eng.device_metric_sums(self.traj[0], self.traj[1])          # [B, T+1, 4] float64
-        w1 = eng.device_wasserstein(self.traj[0], self.traj[1])            # [B, T+1]   float64
+        w1 = eng.device_wasserstein(self.traj[0], self.traj[1], self.w_index, self.w_rows)   # [B, T+1] float64
         local = torch.cat([sums.reshape(self.B, -1), w1], dim=1)
         full = all_gather_rows(local, counts, dim=0) if world > 1 else local
         host = full.cpu().numpy()                                          # syncs the stream
@@ -153,20 +239,82 @@ class Workload:
         vals = eng.batch_scalar_metrics(host[:, : 4 * n].reshape(-1, n, 4), host[:, 4 * n:], H * H, self.E)
         if self.choices is None:
             self.choices = {f"sf={sf}": [list(c) for c in ps[0][0].conv_choices(2 * (ps[0][1][1] - ps[0][1][0]), H, H)]
-                            for sf, ps in zip((TEACHER_SF, STUDENT_SF), self.parts)}
+                            for sf, ps in zip(self.spec["sf"], self.parts)}
         return vals
 
+    def check(self, vals):
+        import numpy as np
+        return {"mean_endpoint_distance": float(np.mean(vals["endpoint_distance"])),
+                "mean_wasserstein": float(np.mean(vals["mean_wasserstein"])), "pairs": int(len(vals["mse"]))}
 
-def cpu_baseline(batch=256, steps=8, pairs=8):
-    """The oracle's restatement of the same loop on the host cores: p_sample_loop semantics (2 passes per
-    step) for teacher and student at ``batch`` samples over the first ``steps`` of the 50 timesteps, plus
-    the metric function on ``pairs`` pairs scaled to the batch.  Reported in the benchmark's unit."""
+
+class GridWorkload:
+    """configs[2]: (size factor x guidance scale x sample) grid on one rank's sample shard (grid.hip_cell_metrics)."""
+
+    def __init__(self, spec, device, rank, batch, concurrent=True):
+        import torch
+        from distillation_trajectories_amd.config import Config
+        from distillation_trajectories_amd.models import DiffusionUNet
+        from distillation_trajectories_amd.synthetic import make_model, noise_table
+        self.torch, self.device, self.B, self.spec, self.rank = torch, device, batch, spec, rank
+        H, T = spec["H"], spec["T"]
+        self.H, self.T = H, T
+        self.cfg = Config()
+        self.cfg.image_size, self.cfg.timesteps, self.cfg.sample_steps = H, T, T
+        self.teacher = make_model(DiffusionUNet, self.cfg, 1.0).to(device)
+        self.students = [make_model(DiffusionUNet, self.cfg, sf).to(device) for sf in spec["sizes"]]
+        first = rank * batch
+        self.table = noise_table(42 + first, batch + T - 1, (1, C, H, H)).reshape(batch + T - 1, -1).to(device)
+        self.first = first
+        self.choices = None
+        self.concurrent = concurrent
+        self.units_per_step = (len(spec["sizes"]) + 1) * len(spec["scales"]) * batch * T
+        self.parts = [[None], [None]]
+
+    def describe(self, world):
+        s = self.spec
+        return {"workload": f"{s['name']}: {len(s['sizes'])} size factors {s['sizes']} x CFG {s['scales']} x {self.B} samples/GPU, "
+                            f"{self.H}x{self.H}x{C}, T={self.T}, generate_trajectory rule (CFG concat for gs > 1), teacher once per "
+                            "CFG plan, metrics of every (student, gs, sample) cell",
+                "batch_per_gpu": self.B, "timesteps": self.T, "image": [C, self.H, self.H], "guidance_scales": s["scales"],
+                "parallelism": f"sample-sharded x{world}, RCCL all-gather of metrics"}
+
+    def step(self, world, counts):
+        from distillation_trajectories_amd import grid
+        local = grid.hip_cell_metrics(self.teacher, self.students, self.cfg, self.spec["scales"], self.first, self.B,
+                                      self.device, table=self.table, streams=None if self.concurrent else 1)
+        full = grid.all_gather_rows(local, counts, dim=2) if world > 1 else local
+        return full.cpu().numpy()
+
+    def check(self, vals):
+        from distillation_trajectories_amd import engine
+        k = engine.SCALAR_KEYS.index("path_length_similarity")
+        return {"path_length_similarity_sf0.5_gs3": float(vals[self.spec["sizes"].index(0.5), self.spec["scales"].index(3.0), :, k].mean()),
+                "cells": int(vals.shape[0] * vals.shape[1] * vals.shape[2])}
+
+
+# ------------------------------------------------------------------------------------------- CPU legs (oracle)
+def _oracle_models(spec):
     from distillation_trajectories_amd.config import Config
     from distillation_trajectories_amd.models import DiffusionUNet
     from distillation_trajectories_amd.synthetic import make_model
-    from oracle import metrics_ref, sampler_ref, unet_ref
+    from oracle import unet_ref
     cfg = Config()
-    cfg.image_size = H
+    cfg.image_size = spec["H"]
+    fns = []
+    for sf, sd in zip(spec["sf"], spec["seeds"]):
+        state = make_model(DiffusionUNet, cfg, sf, seed=sd).state_dict()
+        fns.append(lambda x, t, c, state=state: unet_ref.unet_forward(state, x, t, c))
+    return fns
+
+
+def cpu_baseline(spec, batch=256, steps=8, pairs=8):
+    """The oracle's restatement of the same loop on the host cores: p_sample_loop semantics (2 passes per
+    step) for teacher and student at ``batch`` samples over the first ``steps`` timesteps, plus
+    the metric function on ``pairs`` pairs scaled to the batch.  Reported in the benchmark's unit."""
+    import torch
+    from oracle import metrics_ref, sampler_ref
+    H, T = spec["H"], spec["T"]
     prev_threads = torch.get_num_threads()
     threads = min(16, os.cpu_count() or 1)          # the GPU box's CPU share per GPU
     torch.set_num_threads(threads)
@@ -175,15 +323,13 @@ def cpu_baseline(batch=256, steps=8, pairs=8):
     x0 = torch.randn(batch, C, H, H, generator=g)
     trajs, t_sample = [], 0.0
     with torch.no_grad():
-        for sf in (TEACHER_SF, STUDENT_SF):
-            sd = make_model(DiffusionUNet, cfg, sf).state_dict()
-            fn = lambda x, t, c, sd=sd: unet_ref.unet_forward(sd, x, t, c)   # noqa: E731
+        for fn in _oracle_models(spec):
             x = x0.clone()
             traj = [x]
             fn(x[:2], torch.full((2,), T - 1), None)                        # warm the allocator / oneDNN primitives
             t0 = time.perf_counter()
             for i in range(T - 1, T - 1 - steps, -1):
-                x = sampler_ref.p_sample(fn, x, torch.full((batch,), i, dtype=torch.long), i, params, GUIDANCE,
+                x = sampler_ref.p_sample(fn, x, torch.full((batch,), i, dtype=torch.long), i, params, spec["guidance"],
                                          noise=torch.randn(x.shape, generator=g))
                 traj.append(x)
             t_sample += time.perf_counter() - t0
@@ -191,7 +337,7 @@ def cpu_baseline(batch=256, steps=8, pairs=8):
     t0 = time.perf_counter()
     for b in range(pairs):
         metrics_ref.compute_trajectory_metrics([s[b:b + 1] for s in trajs[0]], [s[b:b + 1] for s in trajs[1]])
-    t_metric_pair = (time.perf_counter() - t0) / pairs * (T + 1) / (steps + 1)   # scaled to 51-state trajectories
+    t_metric_pair = (time.perf_counter() - t0) / pairs * (T + 1) / (steps + 1)   # scaled to T+1-state trajectories
     units = 2 * batch * steps
     # per unit: sampler time + the pair's metric time spread over its 2*T trajectory-timesteps
     sec_per_unit = t_sample / units + t_metric_pair / (2 * T)
@@ -202,29 +348,111 @@ def cpu_baseline(batch=256, steps=8, pairs=8):
                       f"sampler {t_sample:.2f}s, metrics {t_metric_pair * 1e3:.1f} ms/pair"}
 
 
+def cpu_full_length(spec, host_inputs, gpu_vals, gpu_traj, max_seconds=40.0):
+    """Reference-faithful B=1 leg: the oracle's FULL-length loop (all T timesteps, 2 passes per step) for the first
+    pairs of rank 0's batch on the very inputs the GPU used, plus the oracle's metric function on each pair.
+    Returns (b1 timing object, metric_delta_vs_cpu object)."""
+    import numpy as np
+    import torch
+    from distillation_trajectories_amd import engine
+    from oracle import metrics_ref, sampler_ref
+    H, T = spec["H"], spec["T"]
+    x_T, z, idx = host_inputs
+    threads = min(16, os.cpu_count() or 1)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    params = sampler_ref.diffusion_params(T)
+    fns = _oracle_models(spec)
+    per_key, traj_err, done, t_loop, t_met = {}, 0.0, 0, 0.0, 0.0
+    nan_mismatch = 0
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        for b in range(x_T.shape[0]):
+            if done and time.perf_counter() - t_start > max_seconds / 2:
+                break
+            pair = []
+            for m, fn in enumerate(fns):
+                x = x_T[b:b + 1].reshape(1, C, H, H)
+                traj, s = [x], 0
+                t0 = time.perf_counter()
+                for i in idx:
+                    noise = None
+                    if i > 0:
+                        noise = z[s, b:b + 1].reshape(1, C, H, H)
+                        s += 1
+                    x = sampler_ref.p_sample(fn, x, torch.full((1,), i, dtype=torch.long), i, params, spec["guidance"], noise=noise)
+                    traj.append(x)
+                t_loop += time.perf_counter() - t0
+                pair.append(traj)
+                want = torch.stack(traj).reshape(T + 1, -1)
+                traj_err = max(traj_err, float((gpu_traj[m][:, b] - want).abs().max() / want.abs().max()))
+            t0 = time.perf_counter()
+            if C * H * H > 1000:
+                np.random.seed(42 + b + 1)              # the engine's per-sample sub-sampling stream (trajectory_engine.py:93)
+            want = metrics_ref.compute_trajectory_metrics(pair[0], pair[1])
+            t_met += time.perf_counter() - t0
+            for k in engine.SCALAR_KEYS:
+                a, w = float(gpu_vals[k][b]), float(want[k])
+                if np.isnan(a) or np.isnan(w):
+                    nan_mismatch += int(np.isnan(a) != np.isnan(w))
+                    continue
+                if k == "trajectory_mse":               # compared before the ill-conditioned log1p(1 - 1000 mse) (SURVEY §0)
+                    a, w = 1.0 - np.expm1(a), 1.0 - np.expm1(w)
+                per_key[k] = max(per_key.get(k, 0.0), abs(a - w) / max(abs(w), 1e-12))
+            done += 1
+    torch.set_num_threads(prev_threads)
+    units = 2 * done * T
+    b1 = {"value": round(units / (t_loop + t_met), 2), "unit": "trajectory-timesteps/s", "cores": threads, "kind": "port",
+          "sample": f"oracle, B=1 like the reference's loops: {done} pair(s), all {T} timesteps, 2 passes per step, + metric "
+                    f"function per pair; sampler {t_loop:.2f}s, metrics {t_met * 1e3 / max(done, 1):.1f} ms/pair"}
+    delta = {"pairs": done, "timesteps": T, "max_rel": max(per_key.values()) if per_key else None,
+             "worst_key": max(per_key, key=per_key.get) if per_key else None, "nan_position_mismatches": nan_mismatch,
+             "trajectory_max_err_rel_to_max": traj_err, "tolerance": 1e-4,
+             "per_key": {k: float(f"{v:.3g}") for k, v in per_key.items()},
+             "note": "GPU metrics of rank 0's first pairs vs the oracle's full-length CPU loop on the same x_T / z / weights; "
+                     "trajectory_mse compared as 1000 * mean step-MSE (pre-transform)"}
+    return b1, delta
+
+
 def traffic_from_profiles(kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 note), or None if not recorded."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel_name)
-    except (OSError, ValueError):
-        return None
+    for name in ("r02_hbm_traffic.json", "hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                hit = json.load(f).get(kernel_name)
+            if hit:
+                return hit
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))            # before anything below touches the GPU
+    import numpy as np   # noqa: F401
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    # DT_BENCH_DRYRUN=1 (tests/test_bench_launcher.py, no GPU): rendezvous + rank gather over gloo, then stop
+    dry = os.environ.get("DT_BENCH_DRYRUN") == "1"
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # one process per GPU; DT_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the N > 1 path
-    backend = os.environ.get("DT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    backend = "gloo" if dry else os.environ.get("DT_BENCH_BACKEND", "nccl")
+    n_dev = 1 if dry else torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows {n_dev} (set DT_BENCH_BACKEND=gloo "
+                         "to rehearse the multi-rank path on fewer GPUs)")
+    dev_index = local_rank % n_dev
+    device = None
+    if not dry:
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
+    ranks = [{"rank": 0, "local_rank": 0, "device": dev_index, "pid": os.getpid()}]
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -232,13 +460,26 @@ def main():
             dist.init_process_group("nccl", device_id=device)      # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend)
+        me = torch.tensor([rank, local_rank, dev_index, os.getpid()], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+        everyone = [torch.empty_like(me) for _ in range(world)]
+        dist.all_gather(everyone, me)                               # the collective itself shows who is in the job
+        ranks = [{"rank": int(t[0]), "local_rank": int(t[1]), "device": int(t[2]), "pid": int(t[3])} for t in everyone]
     else:
         dist = None
+    if dry:
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": ranks, "backend": backend}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from distillation_trajectories_amd import _hip
     _hip.load()
-    wl = Workload(device, rank, args.batch, concurrent=not args.serial)
-    counts = [args.batch] * world
+    spec = CONFIGS[args.config]
+    batch = args.batch or spec["batch"]
+    wl = (GridWorkload if args.config == 2 else PairWorkload)(spec, device, rank, batch, concurrent=not args.serial)
+    counts = [batch] * world
 
     def barrier():
         if dist is not None:
@@ -267,14 +508,14 @@ def main():
         _hip.profile_begin()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            wl.step(1, [args.batch])
+            wl.step(1, [batch])
         torch.cuda.synchronize()
         profiled_elapsed = time.perf_counter() - t1
         kernels = _hip.profile_end()
     if dist is not None:
         dist.barrier()
 
-    units_per_step = 2 * args.batch * T * world
+    units_per_step = wl.units_per_step * world
     value = units_per_step * args.steps / elapsed
     out = {
         "metric": "trajectory-timesteps/sec (B×T U-Net fwd) at 16×16 T=50",
@@ -283,15 +524,10 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (fp32-accurate; convolutions: exact 3-plane bf16 operand split on bf16 MFMA with fp32 accumulate, or "
                  "native fp32 MFMA, chosen per layer)", "data": "synthetic",
-        "config": {"workload": "configs[1]: teacher sf=1.0 vs student sf=0.5, 16x16x3, T=50, batch 256/GPU, "
-                               "p_sample_loop CFG (2 U-Net passes/step, w=1.0) + trajectory metrics of the 256 pairs",
-                   "batch_per_gpu": args.batch, "timesteps": T, "image": [C, H, H], "guidance_scale": GUIDANCE,
-                   "unet_passes_per_step": 2, "parallelism": f"sample-sharded x{world}, RCCL all-gather of metrics",
-                   "streams_per_gpu": {"teacher_sub_batches": len(wl.parts[0]), "student_sub_batches": len(wl.parts[1])}},
+        "config": wl.describe(world),
         "per_gpu": round(value / world, 1),
-        "metric_check": {"mean_endpoint_distance": float(np.mean(vals["endpoint_distance"])),
-                         "mean_wasserstein": float(np.mean(vals["mean_wasserstein"])),
-                         "pairs": int(len(vals["mse"]))},
+        "ranks": ranks, "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
+        "metric_check": wl.check(vals),
     }
     if kernels:
         # A kernel = one __global__ template; its tile instantiations <BM,BN> are the same code on other tile sizes and
@@ -302,7 +538,7 @@ def main():
             g["ms"] += k["ms"]; g["flops"] += k["flops"]; g["launches"] += k["launches"]; g["members"][n] = k
         dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         total_ms = sum(k["ms"] for k in kernels.values())
-        conv = {n: k for n, k in kernels.items() if n.startswith(("conv_gemm", "conv_strip"))}
+        conv = {n: k for n, k in kernels.items() if n.startswith(("conv_gemm", "conv_strip", "lowres_"))}
         conv_ms, conv_fl = sum(k["ms"] for k in conv.values()), sum(k["flops"] for k in conv.values())
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         split = "bf16x6" in dom_name
@@ -337,8 +573,15 @@ def main():
                               "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["flops"] else None,
                               "gbps": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1) if k["bytes"] else None}
                           for n, k in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != 2:
+        gpu_traj = [t[:, :2].cpu() for t in wl.traj]
+        if args.config == 1:
+            out["cpu_baseline"] = cpu_baseline(spec)
+            b1, delta = cpu_full_length(spec, wl.host_inputs, vals, gpu_traj)
+            out["cpu_baseline"]["b1"] = b1
+            out["metric_delta_vs_cpu"] = delta
+        else:       # configs[4]: one full-length CPU pair would take minutes; a bounded batched sample only
+            out["cpu_baseline"] = cpu_baseline(spec, batch=16, steps=2, pairs=1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

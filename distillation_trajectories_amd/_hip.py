@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 
 COND_NONE, COND_ZERO, COND_ONE = 0, 1, 2
 RULE_ENGINE, RULE_PSAMPLE, RULE_MANAGER = 0, 1, 2
-PREC_FP32, PREC_SPLIT_BF16, PREC_AUTO, PREC_AUTO_PLANES = 0, 1, 2, 3
+PREC_FP32, PREC_SPLIT_BF16, PREC_AUTO = 0, 1, 2
 BT_COUNT, GT_COUNT, N_BLOCKS = 16, 9, 8
 ABI_VERSION = 1
 

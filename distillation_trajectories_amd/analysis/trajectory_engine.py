@@ -88,35 +88,48 @@ def generate_trajectory(model, noise, timesteps, device, seed=None, guidance_sca
 _TEACHER_CACHE = {}
 
 
-def sample_grid(handle, table, first_row, num_samples, timesteps, guidance_scales, H, W):
-    """Trajectories of one model for every (guidance scale, sample): {gs: device tensor [T+1, S, E]}.
+def sample_grid_groups(handle, table, first_row, num_samples, timesteps, guidance_scales, H, W):
+    """Trajectories of one model, one launch sequence per CFG plan: [(scales, traj [T+1, G*S, E])].
 
     ``table`` is the device noise table [rows, E]; sample s starts from row first_row+s and takes
     row first_row+s+t at timestep t.  All guidance scales of one CFG plan share one launch sequence
-    with batch = S x (#scales) and a per-row guidance scale.
+    with batch = S x (#scales) and a per-row guidance scale; the scales that do not take the reference's
+    two-pass branch (gs <= 1, None) all give the same trajectory, so that group has G = 1.
+    Rows [g*S, (g+1)*S) of a group's tensor belong to its g-th scale.
     """
     S, T = num_samples, timesteps
     E = table.shape[1]
     coefs = engine_coefficients(T)
     order = list(range(T - 1, -1, -1))
-    out = {}
     plain = [gs for gs in guidance_scales if not uses_cfg(gs)]
     guided = [gs for gs in guidance_scales if uses_cfg(gs)]
+    groups = []
     for cfg, group in ((False, plain), (True, guided)):
         if not group:
             continue
         G = len(group) if cfg else 1            # without CFG every scale gives the same trajectory
-        rows = torch.arange(S, dtype=torch.int32).repeat(G) + first_row
-        z_row = rows.to(table.device)
+        z_row = (torch.arange(S, dtype=torch.int32).repeat(G) + first_row).to(table.device, non_blocking=True)
         traj = torch.empty(T + 1, G * S, E, dtype=torch.float32, device=table.device)
         traj[0].copy_(table[first_row: first_row + S].repeat(G, 1))
-        w = torch.tensor([float(gs) for gs in group], dtype=torch.float32).repeat_interleave(S).to(table.device) if cfg else None
+        w = None
+        if cfg:
+            w = torch.tensor([float(gs) for gs in group], dtype=torch.float32).repeat_interleave(S).to(table.device, non_blocking=True)
         t_rows, modes, n_pass = _plan(T, cfg)
         tb = handle.time_bias(t_rows, modes)
         handle.sample(RULE_ENGINE, traj, H, W, tb, n_pass, [coefs[t] for t in order], [t > 0 for t in order],
                       z=table, z_row=z_row, z_shift=list(order), w=w)
+        groups.append((list(group), traj))
+    return groups
+
+
+def sample_grid(handle, table, first_row, num_samples, timesteps, guidance_scales, H, W):
+    """{gs: device tensor view [T+1, S, E]} over ``sample_grid_groups``."""
+    S = num_samples
+    out = {}
+    for group, traj in sample_grid_groups(handle, table, first_row, S, timesteps, guidance_scales, H, W):
         for g, gs in enumerate(group):
-            out[gs] = traj[:, (g * S if cfg else 0): (g * S if cfg else 0) + S]
+            lo = g * S if traj.shape[1] > S else 0           # the plain group holds one trajectory for all its scales
+            out[gs] = traj[:, lo: lo + S]
     return out
 
 

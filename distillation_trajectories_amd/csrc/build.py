@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["dt_conv.hip", "dt_conv_bf16.hip", "dt_conv_dma.hip", "dt_conv_strip.hip", "dt_layers.hip", "dt_update.hip", "dt_metrics.hip", "dt_unet.hip"]
+SOURCES = ["dt_conv.hip", "dt_conv_bf16.hip", "dt_conv_strip.hip", "dt_layers.hip", "dt_update.hip", "dt_metrics.hip", "dt_unet.hip"]
 HEADERS = ["dt_internal.h", "dt_conv_epilogue.h", os.path.join("..", "..", "include", "dt_hip.h")]
 LIB = os.path.join(HERE, "libdt_hip.so")
 ARCH = "gfx950"
@@ -24,28 +24,59 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
+OBJ_DIR = os.path.join(HERE, "_build")
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def is_stale():
+    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return _newer(LIB, deps)
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
+    """Compile every HIP source for gfx950 (one object per source, in parallel, only what changed unless
+    ``force``) and link the shared library.  Returns its path."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-rtlib-add-rpath",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(HERE, s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = hipcc_path()
+    common = [os.path.join(HERE, f) for f in HEADERS] + [os.path.abspath(__file__)]
+
+    def compile_one(src):
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        path = os.path.join(HERE, src)
+        if not force and not _newer(obj, [path] + common):
+            return obj, None
+        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return obj, subprocess.run(cmd, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_one, SOURCES))
+    for obj, res in results:
+        if res is None:
+            continue
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError(f"hipcc failed with exit code {res.returncode} on {obj}")
+        if verbose and res.stderr:
+            sys.stderr.write(res.stderr)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-rtlib-add-rpath", "-o", LIB] + [o for o, _ in results]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError(f"hipcc failed with exit code {res.returncode}")
-    if verbose and res.stderr:
-        sys.stderr.write(res.stderr)
+        raise RuntimeError(f"hipcc link failed with exit code {res.returncode}")
     return LIB
 
 

@@ -148,7 +148,7 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
     const ConvChoice c = heuristic_choice(p.M, p.n_p, 1);
     bm = c.bm; bn = c.bn;
   }
-  if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128) || p.n_p % bn) return DT_E_ARG;
+  if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128) || p.n_p % bn || p.prec == 2 || p.prec < 0 || p.prec > 4) return DT_E_ARG;
   const bool tall_m = bm == 128, wide_n = bn == 128;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   if (p.splits < 1 || (p.splits > 1 && !p.slab)) return DT_E_ARG;
@@ -160,11 +160,6 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
     ProfileScope prof(tall_m ? (wide_n ? KC_CONVS_128x128 : KC_CONVS_128x64) : (wide_n ? KC_CONVS_64x128 : KC_CONVS_64x64),
                       flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
     const int st = launch_conv_strip(p, bm, bn, p.prec == 4 ? 2 : 1, s);
-    if (st) return st;
-  } else if (p.prec == 2) {
-    ProfileScope prof(tall_m ? (wide_n ? KC_CONVD_128x128 : KC_CONVD_128x64) : (wide_n ? KC_CONVD_64x128 : KC_CONVD_64x64),
-                      flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
-    const int st = launch_conv_bf16x6_dma(p, bm, bn, s);
     if (st) return st;
   } else if (p.prec == 1) {
     ProfileScope prof(tall_m ? (wide_n ? KC_CONVB_128x128 : KC_CONVB_128x64) : (wide_n ? KC_CONVB_64x128 : KC_CONVB_64x64),
@@ -242,17 +237,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     *reinterpret_cast<float4 *>(p.out + o) = v;
-    if (p.out_pl) {
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-      bf16x4 q1, q2, q3;
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { __bf16 a1, a2, a3; split3(vv[e], a1, a2, a3); q1[e] = a1; q2[e] = a2; q3[e] = a3; }
-      __bf16 *pl = reinterpret_cast<__bf16 *>(p.out_pl) + plane_index(m, n, p.cout_p >> 4);
-      *reinterpret_cast<bf16x4 *>(pl) = q1;
-      *reinterpret_cast<bf16x4 *>(pl + 16) = q2;
-      *reinterpret_cast<bf16x4 *>(pl + 32) = q3;
-    }
   }
 }
 

@@ -10,14 +10,6 @@ namespace dt {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: plain dwordx4 loads, always promoted to VGPRs
 
-// exact three-way bf16 split of one fp32 value: v == a1 + a2 + a3 (round-to-nearest at each step)
-__device__ inline void split3(float v, __bf16 &a1, __bf16 &a2, __bf16 &a3) {
-  a1 = (__bf16)v;
-  const float r1 = v - (float)a1;
-  a2 = (__bf16)r1;
-  a3 = (__bf16)(r1 - (float)a2);
-}
-
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -36,9 +28,6 @@ __device__ inline void split8(const f32x4 lo, const f32x4 hi, bf16x8 &p1, bf16x8
     p1[i] = a1; p2[i] = a2; p3[i] = (__bf16)r2;
   }
 }
-
-// element index of (row m, channel c, plane 0) in a planes tensor with cq = C/16 chunks per row
-__device__ inline size_t plane_index(size_t m, int c, int cq) { return ((m * cq + (c >> 4)) * 3) * 16 + (c & 15); }
 
 template <int MI, int NI>
 __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
@@ -142,12 +131,6 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
         }
         p.out[orow + n] = v;
         vv[ni][r] = v;
-        if (p.out_pl) {
-          __bf16 *pl = reinterpret_cast<__bf16 *>(p.out_pl) + plane_index(m, n, p.cout_p >> 4);
-          __bf16 a1, a2, a3;
-          split3(v, a1, a2, a3);
-          pl[0] = a1; pl[16] = a2; pl[32] = a3;
-        }
       }
     }
     if (p.pool_out) {

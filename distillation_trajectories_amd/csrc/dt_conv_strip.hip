@@ -19,6 +19,7 @@
 //
 // Split-K runs over channel chunks (grid.z slabs, summed in z order by splitk_epilogue_kernel); the block's
 // fused 1x1 skip walk follows as single-tap chunks over in2 / w2, as in the plain kernel.
+#include <mutex>
 #include <type_traits>
 
 #include "dt_conv_epilogue.h"
@@ -286,13 +287,22 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   }
 }
 
+static size_t strip_lds_bytes(int W, int bm, int bn, int kc) {
+  const int R = bm + 2 * (W + 1);
+  return (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 16) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
+}
+
+bool strip_admissible(int W, int bm, int bn, int kc) {
+  if (W + 1 > 64) return false;                                    // 2 strip items per thread cover BM + 2(W+1) <= 256 rows
+  return strip_lds_bytes(W, bm, bn, kc) <= (kc == 2 ? 98304u : 65536u);
+}
+
 int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s) {
   if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || (kc != 1 && kc != 2)) return DT_E_ARG;
   if ((p.cin_p >> 4) % (p.splits * kc) || (p.in2 && (p.cin2_p >> 4) % kc)) return DT_E_ARG;
   if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 strip items per thread cover BM + 2(W+1) <= 256 rows
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
-  const int R = bm + 2 * (p.W + 1);
-  const size_t lds = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 16) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
+  const size_t lds = strip_lds_bytes(p.W, bm, bn, kc);
   if (p.ablate && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
     switch (p.ablate) {
       case 1: conv_strip_bf16x6_kernel<128, 128, 1><<<grid, 256, lds, s>>>(p); break;
@@ -308,14 +318,19 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
     return DT_OK;
   }
   if (kc == 2) {
-    static bool attr_set = false;   // 128x128 needs 80 KB of dynamic LDS
-    if (!attr_set) {
-      DT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 128, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-      DT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 64, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-      DT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 128, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-      DT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 64, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-      attr_set = true;
-    }
+    static std::once_flag attr_once;   // 128x128 needs 80 KB of dynamic LDS; launches come from several host threads
+    static int attr_status = DT_OK;
+    std::call_once(attr_once, [] {
+      const void *fns[4] = {reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 128, 0, 2>),
+                            reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 64, 0, 2>),
+                            reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 128, 0, 2>),
+                            reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 64, 0, 2>)};
+      for (const void *f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        if (e != hipSuccess) attr_status = (int)e;
+      }
+    });
+    if (attr_status != DT_OK) return attr_status;
     if (lds > 98304) return DT_E_SHAPE;
     if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128, 0, 2><<<grid, 256, lds, s>>>(p);
     else if (bm == 128) conv_strip_bf16x6_kernel<128, 64, 0, 2><<<grid, 256, lds, s>>>(p);

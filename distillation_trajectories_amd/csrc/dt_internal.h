@@ -24,7 +24,6 @@ namespace dt {
 enum KernelClass {
   KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
   KC_CONVB_128x128, KC_CONVB_128x64, KC_CONVB_64x128, KC_CONVB_64x64,
-  KC_CONVD_128x128, KC_CONVD_128x64, KC_CONVD_64x128, KC_CONVD_64x64,
   KC_CONVS_128x128, KC_CONVS_128x64, KC_CONVS_64x128, KC_CONVS_64x64,
   KC_SPLITK_EPILOGUE, KC_IM2COL, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
   KC_WASSERSTEIN, KC_RESAMPLE,
@@ -67,7 +66,7 @@ struct ConvParams {
   int splits;
   float *slab;
   int bm, bn;          // tile override (0 = pick by heuristic); bn = 128 needs n_p % 128 == 0
-  int prec;            // 0: exact fp32 MFMA (w = fp32 pack), 1: split-bf16 (w = bf16x3 pack), 2: 1 fed by LDS-DMA,
+  int prec;            // 0: exact fp32 MFMA (w = fp32 pack), 1: split-bf16 (w = bf16x3 pack), 2: unused,
                        // 3: split-bf16 strip kernel (3x3 only; `splits` then divides the channel chunks, not the taps),
                        // 4: strip kernel with two channel chunks (K = 32) per step
   // enc1's 1x1 skip of the C<=4 channel image, recomputed in the epilogue instead of being
@@ -83,10 +82,6 @@ struct ConvParams {
   const float *w2;
   const float *bias2;
   int cin2_p, cin2_real;
-  // bf16 "planes" twins [M][C/16][3][16] of activation tensors (exact 3-way split, see dt_conv_dma.hip):
-  // inputs of the LDS-DMA kernel (prec == 2) and, when out_pl is set, an extra output of the epilogue
-  const void *in_pl, *in2_pl, *zero;
-  void *out_pl;
   // fused 2x2 max pool of the output (encoder conv2, unsplit launches, W in {8, 16}: every pooling window then lies in
   // one lane's accumulator registers): also written, [M/4][cout_p]; nullptr = the separate maxpool_kernel runs
   float *pool_out;
@@ -100,8 +95,9 @@ struct ConvParams {
 
 int launch_conv(const ConvParams &p, hipStream_t s);
 int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s);
-int launch_conv_bf16x6_dma(const ConvParams &p, int bm, int bn, hipStream_t s);
 int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s);   // prec 3 (kc 1) / 4 (kc 2): 3x3 only
+// whether the strip kernel can run a bm x bn tile with kc chunks per step on rows of W pixels (staging reach, LDS)
+bool strip_admissible(int W, int bm, int bn, int kc);
 int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int n_p,
                             int split_c, int split_cp, hipStream_t s);
 struct ConvChoice { int bm, bn, splits, prec, fuse; };
@@ -116,9 +112,9 @@ int launch_pack_linear_rows(const float *w, const float *b, float *wp, float *bp
                             hipStream_t s);
 
 int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, int W, int kp, hipStream_t s);
-int launch_maxpool(const float *in, float *out, void *out_pl, int Bt, int H, int W, int cp, hipStream_t s);
+int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s);
 // skip == nullptr: only the upsampled channels are written (the consumers read the skip half in place)
-int launch_upcat(const float *lo, const float *skip, float *out, void *out_pl, int Bt, int h, int w, int c1p, int c2p,
+int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p,
                  hipStream_t s);
 int launch_head(const float *lo, const float *w, const float *bias, float *lowres, float *eps, int Bt, int h, int w_,
                 int cp, int C, int c_real, hipStream_t s);

@@ -6,20 +6,6 @@
 
 namespace dt {
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-// write 4 consecutive channels (c0 % 4 == 0) of row m as three bf16 planes
-__device__ inline void store_planes4(void *out_pl, size_t m, int c0, int cq, const float4 v) {
-  bf16x4 q1, q2, q3;
-  const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { __bf16 a1, a2, a3; split3(vv[e], a1, a2, a3); q1[e] = a1; q2[e] = a2; q3[e] = a3; }
-  __bf16 *pl = reinterpret_cast<__bf16 *>(out_pl) + plane_index(m, c0, cq);
-  *reinterpret_cast<bf16x4 *>(pl) = q1;
-  *reinterpret_cast<bf16x4 *>(pl + 16) = q2;
-  *reinterpret_cast<bf16x4 *>(pl + 32) = q3;
-}
-
 // First-layer im2col: x[B][C][H][W] (NCHW, shared by all passes) -> patches[n_pass*B*H*W][kp] with
 // k = c*9 + (ky*3+kx) (the flattened OIHW order of conv1.weight), zero padding at the image border and
 // for k >= 9C.  enc1.conv1 then runs as a 1x1 GEMM with K = kp instead of a 9-tap walk over a
@@ -59,7 +45,7 @@ int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, 
 }
 
 // 2x2 max pooling, stride 2, float4 over channels
-__global__ void maxpool_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, void *out_pl, int Bt, int H, int W,
+__global__ void maxpool_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int Bt, int H, int W,
                                int c4) {
   const int Ho = H >> 1, Wo = W >> 1;
   const size_t total = (size_t)Bt * Ho * Wo * c4;
@@ -77,15 +63,14 @@ __global__ void maxpool_kernel(const float4 *__restrict__ in, float4 *__restrict
     o.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(cq.z, d.z));
     o.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(cq.w, d.w));
     out[i] = o;
-    if (out_pl) store_planes4(out_pl, i / c4, c * 4, c4 >> 2, o);
   }
 }
 
-int launch_maxpool(const float *in, float *out, void *out_pl, int Bt, int H, int W, int cp, hipStream_t s) {
+int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s) {
   const size_t total = (size_t)Bt * (H / 2) * (W / 2) * (cp / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   ProfileScope prof(KC_POOL, 0.0, 4.0 * Bt * H * W * cp * 1.25, s);
-  maxpool_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), out_pl, Bt,
+  maxpool_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), Bt,
                                          H, W, cp / 4);
   DT_LAUNCH_CHECK();
   return DT_OK;
@@ -104,7 +89,7 @@ __device__ inline void bilinear_src(int dst, int in, int out, int &i0, int &i1, 
 
 // out[b][y][x][0:c1p] = bilinear_x2(lo[b]), out[...][c1p:c1p+c2p] = skip[b][y][x]  (torch.cat dim=1)
 __global__ void upcat_kernel(const float4 *__restrict__ lo, const float4 *__restrict__ skip, float4 *__restrict__ out,
-                             void *out_pl, int Bt, int h, int w, int c1q, int c2q) {
+                             int Bt, int h, int w, int c1q, int c2q) {
   const int H = 2 * h, W = 2 * w, cq = c1q + c2q;
   const int cw = skip ? cq : c1q;                 // skip == nullptr: only the upsampled channels are written
   const size_t total = (size_t)Bt * H * W * cw;
@@ -132,17 +117,16 @@ __global__ void upcat_kernel(const float4 *__restrict__ lo, const float4 *__rest
       o.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
     }
     out[pixel * cq + c] = o;
-    if (out_pl) store_planes4(out_pl, pixel, c * 4, cq >> 2, o);
   }
 }
 
-int launch_upcat(const float *lo, const float *skip, float *out, void *out_pl, int Bt, int h, int w, int c1p, int c2p,
+int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p,
                  hipStream_t s) {
   const size_t total = (size_t)Bt * 4 * h * w * ((c1p + (skip ? c2p : 0)) / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   ProfileScope prof(KC_UPCAT, 0.0, 4.0 * Bt * h * w * (c1p + 4.0 * c1p + (skip ? 8.0 * c2p : 0.0)), s);
   upcat_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(lo), reinterpret_cast<const float4 *>(skip),
-                                       reinterpret_cast<float4 *>(out), out_pl, Bt, h, w, c1p / 4, c2p / 4);
+                                       reinterpret_cast<float4 *>(out), Bt, h, w, c1p / 4, c2p / 4);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

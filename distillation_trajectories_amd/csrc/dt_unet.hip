@@ -7,6 +7,7 @@
 //   up+cat(enc4) -> dec3 @H/8 -> up+cat(enc3) -> dec2 @H/4 -> up+cat(enc2) -> dec1 @H/2 -> up + 1x1 head @H
 // Each residual block is up to three implicit-GEMM launches (1x1 skip, conv1, conv2) whose epilogues
 // carry BN/ReLU/time-bias/residual, so a forward is 8 blocks * (2..3) + 4 pools + 3 upcats + 2 = ~32 launches.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -35,7 +36,7 @@ namespace {
 struct ProfRecord { hipEvent_t a, b; int cls; double flops, bytes; };
 struct Profiler {
   std::mutex mu;          // launches may come from several host threads (one per stream)
-  bool on = false;
+  std::atomic<bool> on{false};   // read by every launch without the lock
   std::vector<ProfRecord> rec;
   std::vector<hipEvent_t> pool;     // events are recycled between sessions
   size_t used = 0;
@@ -51,8 +52,7 @@ struct Profiler {
 const char *kClassName[KC_COUNT] = {
     "conv_gemm_kernel<128,128>", "conv_gemm_kernel<128,64>", "conv_gemm_kernel<64,128>", "conv_gemm_kernel<64,64>",
     "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
-    "conv_gemm_bf16x6_kernel<64,64>", "conv_gemm_bf16x6_dma_kernel<128,128>", "conv_gemm_bf16x6_dma_kernel<128,64>",
-    "conv_gemm_bf16x6_dma_kernel<64,128>", "conv_gemm_bf16x6_dma_kernel<64,64>",
+    "conv_gemm_bf16x6_kernel<64,64>",
     "conv_strip_bf16x6_kernel<128,128>", "conv_strip_bf16x6_kernel<128,64>", "conv_strip_bf16x6_kernel<64,128>",
     "conv_strip_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
@@ -60,7 +60,7 @@ const char *kClassName[KC_COUNT] = {
 
 namespace dt {
 ProfileScope::ProfileScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
-  if (!g_prof.on) return;
+  if (!g_prof.on.load(std::memory_order_relaxed)) return;
   hipEvent_t a;
   {
     std::lock_guard<std::mutex> lock(g_prof.mu);
@@ -111,10 +111,11 @@ struct LoopGraph {
 
 struct dt_unet {
   std::vector<TunedShape> tuned;
-  std::vector<LoopGraph> graphs;   // replay cache of the sampler loop; dropped whenever the launch plan changes
+  // replay cache of the sampler loop (not part of the handle's logical state, hence mutable + its own lock: the
+  // sampler may be entered from several host threads); dropped whenever the launch plan changes
+  mutable std::vector<LoopGraph> graphs;
+  mutable std::mutex graph_mu;
   int precision;          // DT_PREC_*: which convolution arithmetic the heuristic / autotuner may use
-  bool planes;            // producers also emit bf16 plane twins, enabling the LDS-DMA conv (prec 2)
-  float *zero_page;       // 256 B of zeros inside the slab (source of out-of-image DMA lanes)
   dt_unet_desc desc;
   BlockW blk[kBlocks];
   int cp[4];              // padded dims
@@ -139,7 +140,6 @@ struct Plan {
   size_t h[kBlocks], r[kBlocks], o[kBlocks];   // conv1 out, skip out, block out
   size_t pool[4], cat[3];
   size_t slab, lowres;                         // split-K partial sums; low-resolution head output
-  size_t h_pl[kBlocks], pool_pl[4], cat_pl[3]; // bf16 plane twins (0 when the handle does not use them)
   size_t total;
   int H[kBlocks], W[kBlocks];                  // spatial size of each block
 };
@@ -159,11 +159,6 @@ Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
     if (j >= 1 && j <= 4) p.pool[j - 1] = b.take(px * u->blk[j].cin_p);
     if (j >= 5) p.cat[j - 5] = b.take(px * u->blk[j].cin_p);
     p.h[j] = b.take(px * u->blk[j].cout_p);
-    if (u->planes) {
-      if (j >= 1 && j <= 4) p.pool_pl[j - 1] = b.take(px * u->blk[j].cin_p * 3 / 2);
-      if (j >= 5) p.cat_pl[j - 5] = b.take(px * u->blk[j].cin_p * 3 / 2);
-      p.h_pl[j] = b.take(px * u->blk[j].cout_p * 3 / 2);
-    }
     p.r[j] = (u->blk[j].has_res && j > 0) ? b.take(px * u->blk[j].cout_p) : 0;
     p.o[j] = b.take(px * u->blk[j].cout_p);
     if (j > 0 && px <= (size_t)kSplitMaxRows) {
@@ -178,6 +173,7 @@ Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
 }
 
 void drop_graphs(dt_unet *u) {
+  std::lock_guard<std::mutex> lock(u->graph_mu);
   for (LoopGraph &g : u->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
   u->graphs.clear();
 }
@@ -192,9 +188,6 @@ const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W) {
 // block has no such launch (identity skips, and enc1 whose skip is recomputed in conv2's epilogue).
 bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, const Plan &pl, int Bt, const float *tb,
                int tb_div, const ConvChoice *choice, ConvParams &p) {
-  // plane twin of the block input (pool / concat output); enc1's input are im2col patches (no twin)
-  const void *in_pl = nullptr;
-  if (u->planes && j >= 1) in_pl = ws + (j <= 4 ? pl.pool_pl[j - 1] : pl.cat_pl[j - 5]);
   const BlockW &k = u->blk[j];
   const int h = pl.H[j], w = pl.W[j];
   const bool dot = h == 1 && w == 1;   // a 1x1 image only ever sees the centre tap of a padded 3x3 kernel
@@ -205,8 +198,6 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   p.tb_stride = u->tb_stride; p.m_per_tb = h * w * tb_div;
   p.slab = ws + pl.slab;
   p.in = in;
-  p.in_pl = in_pl;
-  p.zero = u->zero_page;
   int taps = 1;
   if (slot == 0) {
     if (!k.has_res || j == 0) return false;
@@ -214,7 +205,6 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1; p.relu = 0;
   } else if (slot == 1) {
     p.w = k.w1; p.scale = k.s1; p.shift = k.h1; p.tb = tb + k.tb_off; p.out = ws + pl.h[j]; p.relu = 1;
-    if (u->planes) p.out_pl = ws + pl.h_pl[j];      // conv2 may consume the twin through LDS-DMA
     if (j == 0) {
       // enc1: `in` holds the im2col patches, conv1 is a 1x1 GEMM over K = kp0
       p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1;
@@ -224,7 +214,6 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     }
   } else {
     p.in = ws + pl.h[j]; p.cin_p = k.cout_p; p.cin_real = k.cout;
-    p.in_pl = u->planes ? ws + pl.h_pl[j] : nullptr;
     p.w = k.w2; p.scale = k.s2; p.shift = k.h2; p.out = ws + pl.o[j]; p.relu = 1;
     p.ksize = 3; p.tap_lo = dot ? 4 : 0; p.tap_hi = dot ? 5 : 9;
     taps = dot ? 1 : 9;
@@ -238,28 +227,27 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   }
   ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
   if (!choice) {   // untuned default per mode; the strip kernel wherever the full 3x3 walk runs (uniformly >= the plain one)
-    c.prec = u->precision == DT_PREC_FP32 ? 0 : (p.in_pl ? 2 : 1);
-    if (c.prec == 1 && p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && p.W + 1 <= 64) {
+    c.prec = u->precision == DT_PREC_FP32 ? 0 : 1;
+    if (c.prec == 1 && p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && strip_admissible(p.W, 64, 64, 1)) {
       c.prec = 3;
       const int cc = p.cin_p >> 4;   // tap groups 3 / 9 become channel-chunk groups 4 / 8 where they divide
       c.splits = c.splits == 9 ? (cc % 8 == 0 ? 8 : (cc % 4 == 0 ? 4 : 1)) : (c.splits == 3 ? (cc % 4 == 0 ? 4 : (cc % 2 == 0 ? 2 : 1)) : 1);
     }
   }
-  if (c.prec == 2 && !p.in_pl) c.prec = 1;
-  if (c.prec >= 3 && p.tap_hi - p.tap_lo != 9) c.prec = 1;          // the strip kernel is the full 3x3 walk only
+  if (c.prec == 2) c.prec = 1;
+  if (c.prec >= 3 && (p.tap_hi - p.tap_lo != 9 || !strip_admissible(p.W, 64, 64, 1))) c.prec = 1;   // full 3x3 walks of rows <= 63 px only
   if (c.prec == 4 && (p.cin_p >> 4) % 2) c.prec = 3;                // two chunks per step need an even chunk count
   if (p.x3 || j == 0 || p.M > kSplitMaxRows) c.splits = 1;          // (enc1: no slab; its conv2 keeps the fused x3 epilogue)
   if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * (c.prec == 4 ? 2 : 1)) != 0)
                   : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
   // encoder blocks enc1..enc4 feed a 2x2 max pool: folded into this launch's epilogue where the windows are in-lane
-  if (slot == 2 && j <= 3 && c.splits == 1 && !u->planes && (w == 8 || w == 16) && h % 2 == 0) p.pool_out = ws + pl.pool[j];
+  if (slot == 2 && j <= 3 && c.splits == 1 && (w == 8 || w == 16) && h % 2 == 0) p.pool_out = ws + pl.pool[j];
   if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
   if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0 && !(c.prec == 4 && (k.cin_p >> 4) % 2)) {
     // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
     p.add = nullptr;
     p.in2 = in; p.w2 = c.prec >= 1 ? k.wrb : k.wr; p.bias2 = k.hr; p.cin2_p = k.cin_p; p.cin2_real = k.cin;
-    p.in2_pl = in_pl;
   }
   return true;
 }
@@ -269,7 +257,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
 // buffer only ever holds the upsampled half.
 bool concat_in_place(const dt_unet *u, int j, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
                      const TunedShape *tuned) {
-  if (j < 5 || u->planes || !u->blk[j].has_res) return false;
+  if (j < 5 || !u->blk[j].has_res) return false;
   ConvParams c1, c2;
   if (!conv_slot(u, j, 1, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][1] : nullptr, c1)) return false;
   if (!conv_slot(u, j, 2, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][2] : nullptr, c2)) return false;
@@ -318,14 +306,14 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
       ConvParams prev;
       conv_slot(u, j - 1, 2, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j - 1][2] : nullptr, prev);
       if (!prev.pool_out)
-      st = launch_maxpool(ws + pl.o[j - 1], ws + pl.pool[j - 1], u->planes ? ws + pl.pool_pl[j - 1] : nullptr, Bt,
+      st = launch_maxpool(ws + pl.o[j - 1], ws + pl.pool[j - 1], Bt,
                           pl.H[j - 1], pl.W[j - 1], u->blk[j - 1].cout_p, s);
       if (st) return st;
       cur = ws + pl.pool[j - 1];
     } else if (j >= 5) {           // decoder: upsample previous output, concat the matching encoder output
       const int skip = 8 - j;      // dec3<-enc4(3), dec2<-enc3(2), dec1<-enc2(1)
       const bool in_place = concat_in_place(u, j, ws, pl, Bt, tb, tb_div, tuned);
-      st = launch_upcat(ws + pl.o[j - 1], in_place ? nullptr : ws + pl.o[skip], ws + pl.cat[j - 5], u->planes ? ws + pl.cat_pl[j - 5] : nullptr,
+      st = launch_upcat(ws + pl.o[j - 1], in_place ? nullptr : ws + pl.o[skip], ws + pl.cat[j - 5],
                         Bt, pl.H[j - 1], pl.W[j - 1], u->blk[j - 1].cout_p, u->blk[skip].cout_p, s);
       if (st) return st;
       cur = ws + pl.cat[j - 5];
@@ -367,7 +355,6 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   if (!u) return (int)hipErrorOutOfMemory;
   u->desc = *desc;
   u->precision = DT_PREC_AUTO;
-  u->planes = false;
   const int C = desc->channels, D = desc->temb_dim;
   const int *d = desc->dims;
   for (int i = 0; i < 4; ++i) u->cp[i] = round_up(d[i], kChanPad);
@@ -413,7 +400,6 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   const size_t o_w1g = bump.take((size_t)D * D), o_b1g = bump.take(D), o_wc0 = bump.take(D), o_bc0 = bump.take(D);
   const size_t o_wc2 = bump.take((size_t)D * D), o_bc2 = bump.take(D), o_fr = bump.take(half);
   const size_t o_fw = bump.take((size_t)C * d[0]), o_fb = bump.take(C);
-  const size_t o_zero = bump.take(64);
   u->slab_floats = bump.off;
   hipError_t e = hipMalloc((void **)&u->slab, u->slab_floats * sizeof(float));
   if (e != hipSuccess) { delete u; return (int)e; }
@@ -465,8 +451,6 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   u->tw = TembWeights{S + o_fr, S + o_w1g, S + o_b1g, S + o_wc0, S + o_bc0, S + o_wc2, S + o_bc2, S + o_wt, S + o_bt,
                       D, half, tb};
   u->final_w = S + o_fw; u->final_b = S + o_fb;
-  u->zero_page = S + o_zero;
-  if (hipMemsetAsync(u->zero_page, 0, 256, s) != hipSuccess) { (void)hipFree(u->slab); delete u; return (int)hipGetLastError(); }
   *out = u;
   return DT_OK;
 }
@@ -544,10 +528,11 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       // for full 3x3 walks, the plain split-bf16 kernel for everything else, the LDS-DMA kernel where twins exist.
       for (int prec = 0; prec <= 4; ++prec) {
         if (h->precision == DT_PREC_FP32 ? prec != 0 : prec == 0) continue;
-        if (prec == 2 && !p.in_pl) continue;
-        if (prec >= 3 && !full3x3) continue;
+        if (prec == 2) continue;
+        const bool strip_ok = full3x3 && strip_admissible(p.W, 64, 64, 1);   // some strip tile fits this row width
+        if (prec >= 3 && !strip_ok) continue;
         if (prec == 4 && (p.cin_p >> 4) % 2) continue;
-        if (prec == 1 && full3x3) continue;
+        if (prec == 1 && strip_ok) continue;                                  // the plain kernel competes where the strip one cannot run
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
@@ -557,6 +542,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
             if ((prec >= 3 || !walk9) && (p.cin_p >> 4) % (sp * (prec == 4 ? 2 : 1))) continue;
             if (prec == 4 && fuse && (kw.cin_p >> 4) % 2) continue;
+            if (prec >= 3 && !strip_admissible(p.W, bm, bn, prec == 4 ? 2 : 1)) continue;   // LDS footprint of this tile
             if (sp > 1 && tiles * (sp / 2) >= 1024) continue;          // already >= 4 workgroups per CU without this split
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
@@ -564,13 +550,13 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
             if (fuse) {
               q.add = nullptr; q.in2 = in; q.w2 = prec ? kw.wrb : kw.wr; q.bias2 = kw.hr; q.cin2_p = kw.cin_p;
               q.cin2_real = kw.cin;
-              q.in2_pl = (h->planes && j >= 1) ? ws + (j <= 4 ? pl.pool_pl[j - 1] : pl.cat_pl[j - 5]) : nullptr;
-              if (prec == 2 && !q.in2_pl) continue;
             }
             float ms_min = 1e30f;
+            bool admissible = true;
             for (int rep = 0; rep < 4 && st == DT_OK; ++rep) {
               (void)hipEventRecord(e0, s);
               st = launch_conv(q, s);
+              if (st == DT_E_SHAPE || st == DT_E_ARG) { st = DT_OK; admissible = false; break; }   // not a candidate here
               (void)hipEventRecord(e1, s);
               if (hipEventSynchronize(e1) != hipSuccess) st = (int)hipGetLastError();
               float ms = 0.f;
@@ -582,6 +568,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
             // ties within 2 % so that run-to-run timing noise does not flip the plan
             // launches are timed on an idle GPU, where extra workgroups are free; in the sampler other streams fill
             // idle CUs anyway, so a split (slab traffic + one more launch) must win by a margin to be taken
+            if (!admissible || ms_min >= 1e30f) continue;
             static const float split_margin = getenv("DT_TUNE_SPLIT_MARGIN") ? (float)atof(getenv("DT_TUNE_SPLIT_MARGIN")) : 1.1f;
             const float cost = (ms_min + (fuse ? 0.f : (can_fuse ? skip_ms : 0.f))) * (sp > 1 ? split_margin : 1.0f);
             if (cost < best_ms * 1.02f) { best_ms = cost < best_ms ? cost : best_ms; best = ConvChoice{bm, bn, sp, prec, fuse}; }
@@ -637,11 +624,10 @@ int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block
 
 int dt_unet_set_precision(dt_unet *h, int precision) {
   if (!h) return DT_E_NULL;
-  if (precision < DT_PREC_FP32 || precision > DT_PREC_AUTO_PLANES) return DT_E_ARG;
+  if (precision < DT_PREC_FP32 || precision > DT_PREC_AUTO) return DT_E_ARG;
   h->tuned.clear();                               // choices are per arithmetic mode: back to the heuristic plan
   drop_graphs(h);
   h->precision = precision;
-  h->planes = precision == DT_PREC_AUTO_PLANES;   // changes the workspace size: re-query dt_unet_workspace_bytes
   return DT_OK;
 }
 
@@ -676,7 +662,7 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
   if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return DT_E_ARG;
   if (splits < 1 || splits > 9 || prec < 0 || prec > 4 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
   if (splits == 5 || splits == 6 || splits == 7) return DT_E_ARG;
-  if (prec == 2 && !h->planes) return DT_E_ARG;
+  if (prec == 2) return DT_E_ARG;
   if (h->blk[block].n_p % bn) return DT_E_ARG;
   const Plan pl = make_plan(h, batch_total, H, W);
   TunedShape *t = nullptr;
@@ -753,7 +739,7 @@ int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, i
   hipStream_t s = (hipStream_t)stream;
   const char *genv = getenv("DT_GRAPH");
   const bool use_graph = genv && atoi(genv) != 0;
-  if (!use_graph || g_prof.on || n_steps < 4)
+  if (!use_graph || g_prof.on.load() || n_steps < 4)
     return sample_loop(h, rule, B, n_pass, H, W, n_steps, tb, coef, has_noise, z, z_row, z_shift, w, w_scalar, traj,
                        eps_scratch, ws, ws_bytes, s);
   // ---- key: every argument by value (the small host arrays by content)
@@ -764,7 +750,8 @@ int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, i
   put(ints, sizeof(ints)); put(ptrs, sizeof(ptrs)); put(&w_scalar, sizeof(w_scalar)); put(&ws_bytes, sizeof(ws_bytes));
   put(coef, sizeof(float) * 4 * n_steps); put(has_noise, sizeof(int32_t) * n_steps);
   if (z_shift) put(z_shift, sizeof(int64_t) * n_steps);
-  dt_unet *hm = const_cast<dt_unet *>(h);   // the cache is not part of the handle's logical state
+  const dt_unet *hm = h;
+  std::lock_guard<std::mutex> lock(hm->graph_mu);
   for (const LoopGraph &g : hm->graphs)
     if (g.key == key) return (int)hipGraphLaunch(g.exec, s);
   // ---- first call with these arguments: capture the loop, instantiate, keep (at most 8 per handle)

@@ -68,7 +68,7 @@ class UNetHandle:
         self.h = h
         self.tb_stride = self.lib.dt_unet_time_bias_stride(self.h)
         mode = os.environ.get("DT_PRECISION", "auto")
-        check(self.lib.dt_unet_set_precision(self.h, {"fp32": 0, "split-bf16": 1, "auto": 2, "auto-planes": 3}[mode]), "dt_unet_set_precision")
+        check(self.lib.dt_unet_set_precision(self.h, {"fp32": 0, "split-bf16": 1, "auto": 2}[mode]), "dt_unet_set_precision")
         self._ws = {}
         self._tuned = set()
 
@@ -83,14 +83,23 @@ class UNetHandle:
     # ------------------------------------------------------------------ caching per nn.Module
     @staticmethod
     def for_module(module):
-        """Handle cached on the module; rebuilt when any weight tensor was replaced or mutated."""
-        sd = module.state_dict()
-        first = next(iter(sd.values()))
-        _require_cuda(first, "model parameters")
-        key = tuple((v.data_ptr(), v._version) for v in sd.values())
+        """Handle cached on the module; rebuilt when any weight tensor was replaced or mutated.
+
+        The HIP path is inference-only (BatchNorm running statistics, no dropout, no autograd): a module left in
+        train mode -- the reference's samplers never call ``eval()`` themselves (utils/diffusion.py:102-212) --
+        would give different numbers in the reference, so that is reported once per module."""
+        tensors = list(module.parameters()) + list(module.buffers())
+        _require_cuda(tensors[0], "model parameters")
+        if module.training and not module.__dict__.get("_dt_hip_train_warned"):
+            import warnings
+            module.__dict__["_dt_hip_train_warned"] = True
+            warnings.warn("distillation_trajectories_amd: the model is in train mode, but the HIP path is inference-only "
+                          "(BatchNorm running statistics, dropout off); call model.eval() as the reference's callers do",
+                          RuntimeWarning, stacklevel=3)
+        key = tuple((v.data_ptr(), v._version) for v in tensors)
         cached = module.__dict__.get("_dt_hip_handle")
         if cached is None or cached[0] != key:
-            cached = (key, UNetHandle(sd, first.device))
+            cached = (key, UNetHandle(module.state_dict(), tensors[0].device))
             module.__dict__["_dt_hip_handle"] = cached
         return cached[1]
 
@@ -102,17 +111,16 @@ class UNetHandle:
             n = self.lib.dt_unet_workspace_bytes(self.h, batch_total, H, W)
             if n == 0:
                 raise HipLibraryError(f"unsupported shape batch={batch_total} H={H} W={W} (H, W must be multiples of 16)")
-            if len(self._ws) > 4:
+            if len(self._ws) > 8:
+                torch.cuda.synchronize(self.device)     # a buffer may still be in use on another stream
                 self._ws.clear()
             ws = self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
         return ws
 
     def set_precision(self, mode):
-        """PREC_FP32 (exact fp32 MFMA), PREC_SPLIT_BF16 (3-plane bf16 split, 6 products), PREC_AUTO, or
-        PREC_AUTO_PLANES (AUTO + pre-split plane twins feeding the LDS-DMA kernel)."""
+        """PREC_FP32 (exact fp32 MFMA), PREC_SPLIT_BF16 (3-plane bf16 split, 6 products) or PREC_AUTO."""
         check(self.lib.dt_unet_set_precision(self.h, int(mode)), "dt_unet_set_precision")
         self._tuned.clear()
-        self._ws.clear()                 # the workspace layout depends on whether plane twins are kept
 
     def autotune(self, batch_total, H, W):
         """Measure tile / tap-split candidates for this forward shape once and keep the fastest (dt_unet_autotune)."""
@@ -141,7 +149,7 @@ class UNetHandle:
                                                    ctypes.byref(sp), ctypes.byref(pr), ctypes.byref(tu)), "dt_unet_conv_choice")
                 if bm.value:
                     out.append((BLOCK_NAMES[j], ("skip", "conv1", "conv2")[slot], bm.value, bn.value, sp.value,
-                                ("fp32", "split-bf16", "split-bf16-dma", "split-bf16-strip", "split-bf16-strip32")[pr.value & 7]
+                                ("fp32", "split-bf16", "-", "split-bf16-strip", "split-bf16-strip32")[pr.value & 7]
                                 + ("+skip" if pr.value & 8 else ""), bool(tu.value)))
         return out
 

@@ -47,29 +47,107 @@ def all_gather_rows(local, counts, dim):
     return torch.cat([p.narrow(dim, 0, c) for p, c in zip(parts, counts)], dim=dim)
 
 
-def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, count, device):
-    """float64 tensor [n_sf, n_gs, count, K] on ``device`` for samples first_sample .. +count-1 (seed 42+s)."""
+def _upload(host):
+    """Host tensor -> current device through pinned memory, asynchronously on the current stream."""
+    return host.pin_memory().to(torch.device("cuda", torch.cuda.current_device()), non_blocking=True)
+
+
+def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, count, device, table=None, streams=None):
+    """float64 tensor [n_sf, n_gs, count, K] on ``device`` for samples first_sample .. +count-1 (seed 42+s).
+
+    The teacher runs once per CFG plan on the current stream.  The students are independent of each other and of
+    the teacher until the metric reductions, so they are spread over ``streams`` side streams (default
+    DT_GRID_STREAMS or 3), one host thread each: the small students, whose launches cannot fill 256 CUs, overlap
+    the big ones.  Every device result stays in HBM until ONE device-to-host copy at the end; the scalar
+    post-transforms then run once, vectorised over every (student, scale, sample) row.
+    ``table``: the device noise table [count+T-1, E] when the caller already holds it (bench.py).
+    """
+    import os
+    import threading
+    from .analysis.metrics.trajectory_metrics import wasserstein_index_tables
+    from .analysis.trajectory_engine import sample_grid_groups
     C, H, T = cfg.channels, cfg.image_size, cfg.timesteps
-    state = torch.get_rng_state()
-    table = noise_table(42 + first_sample, count + T - 1, (1, C, H, H)).reshape(count + T - 1, -1).to(device)
-    torch.set_rng_state(state)
-    th = engine.UNetHandle.for_module(teacher)
-    t_traj = sample_grid(th, table, 0, count, T, guidance_scales, H, H)
-    out = torch.empty(len(students), len(guidance_scales), count, K, dtype=torch.float64, device=device)
-    for i, student in enumerate(students):
-        s_traj = sample_grid(engine.UNetHandle.for_module(student), table, 0, count, T, guidance_scales, H, H)
-        for j, gs in enumerate(guidance_scales):
-            X, Y = t_traj[gs].contiguous(), s_traj[gs].contiguous()
-            sums = engine.device_metric_sums(X, Y).cpu().numpy()
-            if X.shape[2] > 1000:
-                from .analysis.metrics.trajectory_metrics import wasserstein_index_tables
-                tables, rows = wasserstein_index_tables([42 + first_sample + s for s in range(count)], T + 1, X.shape[2])
-                w1 = engine.device_wasserstein(X, Y, tables.to(device), rows.to(device)).cpu().numpy()
-            else:
-                w1 = engine.device_wasserstein(X, Y).cpu().numpy()
-            vals = engine.batch_scalar_metrics(sums, w1, H * H, X.shape[2])
-            out[i, j] = torch.from_numpy(np.stack([vals[k] for k in engine.SCALAR_KEYS], axis=1)).to(device)
-    return out
+    scales = list(guidance_scales)
+    n = T + 1
+    with torch.cuda.device(device):
+        if table is None:
+            table = _upload(noise_table(42 + first_sample, count + T - 1, (1, C, H, H)).reshape(count + T - 1, -1))
+        E = table.shape[1]
+        index = index_row = None
+        if E > 1000:
+            tables, rows = wasserstein_index_tables([42 + first_sample + s for s in range(count)], n, E)
+            index, index_row = _upload(tables), rows
+        handles = [engine.UNetHandle.for_module(m) for m in [teacher] + list(students)]
+        # launch-plan autotuning times kernels with events: do it before anything runs concurrently
+        plans = [(1, count)] + ([(2, count * sum(1 for gs in scales if gs is not None and gs > 1.0))] if any(
+            gs is not None and gs > 1.0 for gs in scales) else [])
+        for h in handles:
+            for n_pass, B in plans:
+                if B and h._wants_tuning(n_pass * B, H, H, None):
+                    tb = h.time_bias([T - 1] * n_pass, [0] * n_pass)
+                    x = table[torch.arange(B, device=device) % table.shape[0]]        # real noise: zeros clock differently
+                    h.forward(x.reshape(B, C, H, H), tb, n_pass, B, tune=True)
+        main = torch.cuda.current_stream()
+        t_groups = sample_grid_groups(handles[0], table, 0, count, T, scales, H, H)
+        teacher_done = torch.cuda.Event()
+        teacher_done.record(main)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        row_sets = []
+        for group, X in t_groups:
+            G = X.shape[1] // count
+            row_sets.append(None if index_row is None else index_row.repeat(G).to(device, non_blocking=True))
+        n_streams = max(1, min(len(students), streams or int(os.environ.get("DT_GRID_STREAMS", "3"))))
+        side = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        results = [None] * len(students)
+        errors = []
+        order = sorted(range(len(students)), key=lambda i: -sum(p.numel() for p in students[i].parameters()))
+        lock = threading.Lock()
+
+        def worker(k):
+            try:
+                with torch.cuda.device(device), torch.cuda.stream(side[k]):
+                    side[k].wait_event(ready)
+                    while True:
+                        with lock:
+                            if not order:
+                                return
+                            i = order.pop(0)
+                        s_groups = sample_grid_groups(handles[1 + i], table, 0, count, T, scales, H, H)
+                        side[k].wait_event(teacher_done)
+                        parts = []
+                        for (_, X), (_, Y), rows in zip(t_groups, s_groups, row_sets):
+                            sums = engine.device_metric_sums(X, Y)                       # [G*S, n, 4]
+                            w1 = engine.device_wasserstein(X, Y, index, rows)            # [G*S, n]
+                            parts.append(torch.cat([sums.reshape(X.shape[1], -1), w1], dim=1))
+                        results[i] = torch.cat(parts, dim=0)
+            except Exception as e:       # surfaced on the calling thread
+                errors.append(e)
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_streams)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        for st in side:
+            main.wait_stream(st)
+        host = torch.stack(results).cpu().numpy()                   # the one D2H: [n_sf, rows, 5n] float64
+    n_sf, n_rows = host.shape[0], host.shape[1]
+    flat = host.reshape(n_sf * n_rows, 5 * n)
+    vals = engine.batch_scalar_metrics(flat[:, : 4 * n].reshape(-1, n, 4), flat[:, 4 * n:], H * H, E)
+    per_row = np.stack([vals[k] for k in engine.SCALAR_KEYS], axis=1).reshape(n_sf, n_rows, K)
+    out = np.empty((n_sf, len(scales), count, K))
+    base = 0
+    for group, X in t_groups:
+        G = X.shape[1] // count
+        for g, gs in enumerate(group):
+            lo = base + (g * count if G > 1 else 0)
+            for j, s in enumerate(scales):
+                if s == gs or (s is None and gs is None):
+                    out[:, j] = per_row[:, lo: lo + count]
+        base += X.shape[1]
+    return torch.from_numpy(out).to(device)
 
 
 def grid_metrics(teacher, students, cfg, guidance_scales, num_samples, rank=0, world=1, device=None, cell_fn=None):

@@ -46,8 +46,9 @@ class SinusoidalPositionEmbeddings(nn.Module):
     """Parameter-free placeholder at index 0 of ``time_mlp`` (keeps key ``time_mlp.1.*``).
 
     The embedding itself (reference models.py:15-39) is evaluated on the device by
-    ``dt_temb_table`` (csrc/dt_embed.hip); ``frequencies`` reproduces the host-side
-    frequency vector so that the device only does ``sin/cos(t * f_k)``.
+    ``time_bias_kernel`` (csrc/dt_layers.hip, C entry ``dt_unet_time_bias``) together with the time /
+    condition MLPs; ``frequencies`` reproduces the host-side frequency vector so that the device only
+    does ``sin/cos(t * f_k)``.
     """
 
     def __init__(self, dim):

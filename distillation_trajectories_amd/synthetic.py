@@ -31,10 +31,11 @@ def model_seed(size_factor):
     return 1000 + round(100 * size_factor)
 
 
-def make_model(model_cls, cfg, size_factor, bn_seed=7, quiet=True):
-    """Seeded random-init model in eval mode with randomised BN (see module docstring)."""
+def make_model(model_cls, cfg, size_factor, bn_seed=7, quiet=True, seed=None):
+    """Seeded random-init model in eval mode with randomised BN (see module docstring); ``seed`` overrides
+    the size-factor-derived seed (two different models of one size factor)."""
     import contextlib, io
-    torch.manual_seed(model_seed(size_factor))
+    torch.manual_seed(model_seed(size_factor) if seed is None else seed)
     with (contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()):
         m = model_cls(cfg, size_factor)
     return randomize_bn(m.eval(), bn_seed)

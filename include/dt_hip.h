@@ -128,7 +128,7 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
                             int splits, int prec, int fuse);
 
 /* tuning aid: time ONE convolution launch (block, slot) of a forward shape under an explicit choice
- * (prec: 0 fp32 MFMA, 1 split-bf16, 2 split-bf16 via LDS-DMA); averages `reps` launches with HIP events */
+ * (prec: 0 fp32 MFMA, 1 split-bf16, 3 / 4 split-bf16 strip kernel with K = 16 / 32 per step); averages `reps` launches with HIP events */
 int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn,
                       int splits, int prec, int fuse, int reps, void *workspace_dev, size_t workspace_bytes,
                       void *stream, float *ms, double *flops);
@@ -137,11 +137,9 @@ int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block
  * (v_mfma_f32_32x32x2_f32); DT_PREC_SPLIT_BF16 splits every fp32 operand exactly into three bf16
  * planes and sums the six significant plane products on the bf16 matrix cores (fp32 accumulate; the
  * dropped cross terms are < 2^-25 relative).  DT_PREC_AUTO (default) lets the autotuner pick per layer.
- * DT_PREC_AUTO_PLANES additionally makes every activation producer emit an exact bf16 "planes" twin
- * [M][C/16][3][16] so that the split-bf16 kernels can be fed by LDS-DMA (global_load_lds) without
- * re-splitting in the consumer; it enlarges the workspace (call dt_unet_workspace_bytes again).  Measured
- * on MI355X it ties the in-consumer split on the large layers and loses the twin-write time, hence opt-in. */
-enum { DT_PREC_FP32 = 0, DT_PREC_SPLIT_BF16 = 1, DT_PREC_AUTO = 2, DT_PREC_AUTO_PLANES = 3 };
+ * (Round 1 also carried an LDS-DMA variant fed by pre-split bf16 "plane twin" tensors; it tied the in-consumer
+ * split on the large layers and lost the twin-write time, so it was removed.) */
+enum { DT_PREC_FP32 = 0, DT_PREC_SPLIT_BF16 = 1, DT_PREC_AUTO = 2 };
 int dt_unet_set_precision(dt_unet *h, int precision);
 
 /* test hook: float offset / padded channel count of a block output inside the workspace

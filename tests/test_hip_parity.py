@@ -160,13 +160,11 @@ def test_unet_forward_large_batch_properties(gpu_models):
     with torch.no_grad():
         want = unet_ref.unet_forward(sd, x[:4].cpu(), torch.full((4,), 17), torch.ones(4, 1))
     assert_close(both[256:260].cpu().numpy(), want.numpy(), what="cond rows")
-    for mode in (_hip.PREC_FP32, _hip.PREC_SPLIT_BF16, _hip.PREC_AUTO_PLANES):
+    for mode in (_hip.PREC_FP32, _hip.PREC_SPLIT_BF16):
         h.set_precision(mode)                        # also drops the tuned plan
         plain = h.forward(x, tb, 2, 256, tune=False)
         kinds = {c[5] for c in h.conv_choices(512, 16, 16)}
         assert any(k.endswith("+skip") for k in kinds), kinds     # the fused-skip walk is exercised
-        if mode == _hip.PREC_AUTO_PLANES:
-            assert any("dma" in k for k in kinds), kinds           # LDS-DMA kernel fed by the plane twins
         assert_close(plain[256:260].cpu().numpy(), want.numpy(), what=f"heuristic plan, mode {mode}")
     h.set_precision(_hip.PREC_AUTO)
 
@@ -522,14 +520,13 @@ def test_conv_arithmetic_accuracy_vs_float64(models):
     m = copy.deepcopy(models(0.5)).to(DEV)
     h = engine.UNetHandle.for_module(m)
     errs = {}
-    for name, mode in (("fp32", _hip.PREC_FP32), ("split-bf16", _hip.PREC_SPLIT_BF16), ("split-bf16-dma", _hip.PREC_AUTO_PLANES)):
+    for name, mode in (("fp32", _hip.PREC_FP32), ("split-bf16", _hip.PREC_SPLIT_BF16)):
         h.set_precision(mode)
         got = m(x.to(DEV), t.to(DEV), torch.ones(16, 1, device=DEV)).double().cpu()
         errs[name] = ((got - want).norm() / want.norm()).item()
     h.set_precision(_hip.PREC_AUTO)
     print("relative L2 error vs float64:", errs)
     assert max(errs.values()) < 2e-6, errs
-    assert errs["split-bf16-dma"] <= 2.0 * errs["fp32"] + 1e-7, errs
     assert errs["split-bf16"] <= 2.0 * errs["fp32"] + 1e-7, errs
 
 
