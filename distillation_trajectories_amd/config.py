@@ -47,7 +47,11 @@ class Config:
         self.trajectory_dir = os.path.join(self.data_dir, "trajectories")
         self.analysis_dir = os.path.join(self.output_dir, "analysis")
         self.metrics_dir = os.path.join(self.analysis_dir, "metrics")
-        self.time_dependent_dir = os.path.join(self.analysis_dir, "time_dependent")
+        # the remaining analysis sub-directories of reference config/config.py:52-62 (names only; nothing in this
+        # package writes there, the unchanged plotting callers do)
+        for name in ("model_comparisons", "time_dependent", "size_dependent", "dimensionality", "latent_space",
+                     "attention", "noise_prediction", "denoising", "fid"):
+            setattr(self, f"{name}_dir", os.path.join(self.analysis_dir, name))
 
         # distillation step counts (reference config/config.py:65-70)
         self.distill = True

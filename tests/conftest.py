@@ -35,6 +35,15 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_r02():
+    """(arrays, meta) of tests/golden/make_golden_r02.py: real-size forwards, configs[0] / [4] loops, configs[2] cells."""
+    arrays = np.load(os.path.join(GOLDEN, "reference_vectors_r02.npz"))
+    with open(os.path.join(GOLDEN, "reference_vectors_r02.json")) as f:
+        meta = json.load(f)
+    return arrays, meta
+
+
+@pytest.fixture(scope="session")
 def models():
     """Seeded synthetic models (CPU weight containers), keyed by size factor; digests checked against golden."""
     from distillation_trajectories_amd.config import Config

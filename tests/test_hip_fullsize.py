@@ -5,6 +5,7 @@ configs[4]: 32x32 (CIFAR shape), teacher, CFG 7 -- forward parity and a short lo
 configs[2]/[3]: size sweep x CFG grid through grid.grid_metrics on one rank.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -139,3 +140,262 @@ def test_config3_grid_one_rank_matches_compare_trajectories(models):
             for k, v in res[gs].items():
                 a, b = grid[i][gs][k], v
                 assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-9 * max(abs(b), 1e-12), (i, gs, k, a, b)
+
+
+# ------------------------------------------------------------------ round 2: parity at the benchmark's own model sizes
+def _close(got, want, rtol, atol, what):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.all(err <= tol), f"{what}: max err {err.max():.3e} at tol {tol.flat[err.argmax()]:.3e} (max |want| {np.abs(want).max():.3e})"
+
+
+def _check_metric_dict(got, want, rel, what):
+    """Reference metric dict (json) vs ours: scalars and per-step lists within ``rel``, identical NaN positions,
+    trajectory_mse on its pre-transform quantity 1000 * mean step-MSE = 1 - expm1(value)."""
+    assert set(got) == set(want), what
+    for k, w in want.items():
+        g = got[k]
+        if isinstance(w, list):
+            assert len(g) == len(w), (what, k)
+            _close(g, w, rel, 1e-7, f"{what} {k}")
+        elif isinstance(w, float) and np.isnan(w):
+            assert np.isnan(float(g)), (what, k)
+        elif k == "trajectory_mse":
+            _close(1.0 - np.expm1(float(g)), 1.0 - np.expm1(float(w)), rel, 1e-9, f"{what} {k} (pre-transform)")
+        else:
+            _close(float(g), float(w), rel, 1e-9, f"{what} {k}")
+
+
+def test_pair3_real_size_trajectories_and_metrics(golden, models):
+    """Teacher sf=1.0 vs student sf=0.5, gs=3, seed 46, T=50 (reference analysis/trajectory_engine.py:24-115): the
+    HIP loop's 51 states against the reference's, then the metrics of the HIP trajectories against pair3.metrics."""
+    from distillation_trajectories_amd.analysis.metrics.trajectory_metrics import compute_trajectory_metrics
+    from distillation_trajectories_amd.analysis.trajectory_engine import generate_trajectory
+    from distillation_trajectories_amd.synthetic import seeded_noise
+    arrays, meta = golden
+    c = next(m for m in meta["metric_cases"] if m["key"] == "pair3")
+    assert (c["teacher_sf"], c["student_sf"], c["gs"], c["seed"], c["T"]) == (1.0, 0.5, 3.0, 46, 50)
+    noise = seeded_noise(c["seed"], (1, 3, 16, 16))
+    trajs = {}
+    for who, sf in (("teacher", 1.0), ("student", 0.5)):
+        m = copy.deepcopy(models(sf)).to(DEV)
+        tr = generate_trajectory(m, noise, c["T"], torch.device(DEV), seed=c["seed"], guidance_scale=c["gs"])
+        want = arrays[f"pair3_{who}"]
+        got = torch.stack(tr).numpy()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[-1], got[-2])
+        # error growth over the 50 dependent steps: reported per step against the state's own scale
+        rel = np.abs(got - want).reshape(len(want), -1).max(1) / np.abs(want).reshape(len(want), -1).max(1)
+        print(f"pair3 {who}: max |err| / max |state| per step: first {rel[1]:.2e}, mid {rel[25]:.2e}, last {rel[-1]:.2e}")
+        _close(got, want, 1e-4, 1e-4 * float(np.abs(want).max()), f"pair3 {who} trajectory")
+        trajs[who] = tr
+    _check_metric_dict(compute_trajectory_metrics(trajs["teacher"], trajs["student"]), c["metrics"], 1e-4, "pair3")
+
+
+def test_r02_forward_all_size_factors_golden(golden_r02, models):
+    """Every size factor of configs[2] the first fixture file lacks (channels 16 ... 230, models.py:101-110)."""
+    arrays, meta = golden_r02
+    seen = set()
+    for c in meta["forward_cases"]:
+        m = copy.deepcopy(models(c["sf"])).to(DEV)
+        x = seeded_noise_(c["seed"], (c["b"], 3, c["h"], c["h"]))
+        t = torch.full((c["b"],), c["t"], dtype=torch.long)
+        cond = None if c["cond"] == "none" else torch.full((c["b"], 1), 0.0 if c["cond"] == "zero" else 1.0)
+        y = m(x.to(DEV), t.to(DEV), None if cond is None else cond.to(DEV))
+        _close(y.cpu().numpy(), arrays[c["key"]], 1e-4, 2e-5, str(c))
+        seen.add(c["sf"])
+    assert seen == {0.05, 0.1, 0.3, 0.4, 0.6, 0.7, 0.75, 0.8, 0.9}
+
+
+def seeded_noise_(seed, shape):
+    from distillation_trajectories_amd.synthetic import seeded_noise
+    return seeded_noise(seed, shape)
+
+
+def test_r02_config0_teacher_loop_golden(golden_r02, models):
+    """configs[0]: teacher p_sample_loop, B=8, T=50 against the reference's whole trajectory."""
+    from distillation_trajectories_amd.utils.diffusion import get_diffusion_params, p_sample_loop
+    arrays, meta = golden_r02
+    c = meta["config0_case"]
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = 16, c["timesteps"]
+    m = copy.deepcopy(models(c["sf"])).to(DEV)
+    torch.manual_seed(c["global_seed"])
+    img, tr = p_sample_loop(m, (c["b"], 3, 16, 16), c["sample_steps"], get_diffusion_params(c["sample_steps"], cfg),
+                            device=torch.device(DEV), config=cfg, track_trajectory=True, guidance_scale=c["w"])
+    got, want = torch.stack(tr).numpy(), arrays[c["key"]]
+    rel = np.abs(got - want).reshape(len(want), -1).max(1) / np.abs(want).reshape(len(want), -1).max(1)
+    print(f"config0 teacher: max |err| / max |state| per step: first {rel[1]:.2e}, mid {rel[25]:.2e}, last {rel[-1]:.2e}")
+    _close(got, want, 1e-4, 1e-4 * float(np.abs(want).max()), "configs[0] teacher trajectory")
+
+
+def test_r02_config4_tail_golden(golden_r02, models):
+    """configs[4]: 32x32, T=1000, w=7.  The random-init teacher is unstable under w=7 (states reach 3e9 in the
+    reference too), so the comparison is made where it is meaningful: (a) every one of the last 50 steps restarted
+    from the reference's own state (50 different (t, state) pairs through U-Net + CFG mix + update), (b) the
+    free-running 50-step tail from the reference's state after 950 steps."""
+    from distillation_trajectories_amd._hip import RULE_PSAMPLE
+    from distillation_trajectories_amd.utils.diffusion import get_diffusion_params, psample_coefficients, timestep_indices
+    arrays, meta = golden_r02
+    c = meta["config4_case"]
+    tail = arrays[c["key"]]
+    B, H, E, T, first = c["b"], c["h"], 3 * c["h"] * c["h"], c["sample_steps"], c["first_entry"]
+    shape = (B, 3, H, H)
+    torch.manual_seed(c["global_seed"])
+    torch.randn(shape)
+    zs = torch.stack([torch.randn(shape) for _ in range(T - 1)]).reshape(T - 1, B, E)
+    idx = timestep_indices(T, c["timesteps"])
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = H, c["timesteps"]
+    coef = psample_coefficients(get_diffusion_params(T, cfg), idx)
+    h = engine.UNetHandle.for_module(copy.deepcopy(models(c["sf"])).to(DEV))
+    n = T - first
+    # (a) teacher-forced single steps
+    worst = 0.0
+    for k in range(first, T):
+        tr = _loop_from(h, torch.from_numpy(tail[k - first]).reshape(B, E), zs[k:k + 1] if idx[k] > 0 else None, [idx[k]], [coef[k]],
+                        c["w"], B, E, H)
+        got, want = tr[1].cpu().numpy().reshape(shape), tail[k - first + 1]
+        worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))
+        _close(got, want, 1e-4, 1e-4 * float(np.abs(want).max()), f"configs[4] single step {k} (t={idx[k]})")
+    # (b) free-running tail
+    tr = _loop_from(h, torch.from_numpy(tail[0]).reshape(B, E), zs[first:], idx[first:], coef[first:], c["w"], B, E, H)
+    got = tr.cpu().numpy().reshape(n + 1, *shape)
+    rel = np.abs(got - tail).reshape(n + 1, -1).max(1) / np.abs(tail).reshape(n + 1, -1).max(1)
+    print(f"configs[4]: single-step worst {worst:.2e}; free-running tail max |err| / max |state|: step 1 {rel[1]:.2e}, "
+          f"25 {rel[25]:.2e}, 50 {rel[-1]:.2e}")
+    assert np.isfinite(got).all()
+    assert rel.max() < 5e-3, rel      # an unstable map amplifies fp32 re-association noise; (a) is the parity check
+
+
+def _loop_from(h, x0, z, idx, coef, w, B, E, H):
+    from distillation_trajectories_amd._hip import COND_NONE, COND_ONE, RULE_PSAMPLE
+    n = len(idx)
+    traj = torch.empty(n + 1, B, E, device=DEV)
+    traj[0].copy_(x0)
+    has_noise = [i > 0 for i in idx]
+    shift, k = [], 0
+    for f in has_noise:
+        shift.append(k * B)
+        k += int(f)
+    zd = z.reshape(-1, E).to(DEV) if z is not None and len(z) else None
+    tb = h.time_bias([i for i in idx for _ in (0, 1)], [COND_NONE, COND_ONE] * n)
+    h.sample(RULE_PSAMPLE, traj, H, H, tb, 2, coef, has_noise, z=zd, z_shift=shift, w_scalar=w)
+    return traj
+
+
+def test_config2_full_size_sweep_grid(golden_r02, models):
+    """configs[2]: all 11 size factors x CFG {1,3,7,20} through grid_metrics (2 samples, T=50); the (0.6, 0.9) x (1, 7)
+    cells against the reference's compare_trajectories (scripts/analysis/analyze_trajectory_metrics.py:476-505)."""
+    from distillation_trajectories_amd.grid import grid_metrics
+    from distillation_trajectories_amd.utils.metric_transformations import transform_metrics
+    _, meta = golden_r02
+    sizes = [0.01, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]
+    scales = [1.0, 3.0, 7.0, 20.0]
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = 16, 50
+    teacher = copy.deepcopy(models(1.0)).to(DEV)
+    students = [copy.deepcopy(models(sf)).to(DEV) for sf in sizes]
+    grid = grid_metrics(teacher, students, cfg, scales, num_samples=2, rank=0, world=1)
+    assert len(grid) == len(sizes)
+    for i, sf in enumerate(sizes):
+        for gs in scales:
+            cell = grid[i][gs]
+            assert set(cell) == set(engine.SCALAR_KEYS)
+            for k, v in cell.items():
+                assert np.isfinite(v) or k == "trajectory_mse", (sf, gs, k, v)
+            t = transform_metrics(cell["path_length_similarity"], cell["trajectory_mse"], cell["mean_directional_consistency"],
+                                  cell["distribution_similarity"])
+            assert all(0.0 <= float(t[k]) <= 1.0 or np.isnan(t[k]) for k in ("trajectory_mse", "distribution_similarity"))
+    # the sf = 1.0 "student" has the teacher's weights: the same trajectories up to the two handles' own launch plans
+    for gs in scales:
+        assert grid[-1][gs]["endpoint_distance"] < 1e-3 and grid[-1][gs]["mean_wasserstein"] < 1e-5, grid[-1][gs]
+    for c in meta["grid_cells"]:
+        i = sizes.index(c["student_sf"])
+        for gs in c["guidance_scales"]:
+            want = c["result"]["student_metrics"][str(gs)]
+            got = {k: grid[i][gs][k] for k in want}
+            assert set(want) == set(engine.SCALAR_KEYS)
+            _check_metric_dict(got, want, 1e-4, f"grid cell sf={c['student_sf']} gs={gs}")
+
+
+def test_forward_64x64_autotuned(models):
+    """64-pixel rows: the strip kernel cannot stage W + 1 = 65 halo pixels at the top level, so the autotuner must
+    fall back to the plain kernel there instead of failing (batch 4 x 64 x 64 = 16384 rows is where tuning starts)."""
+    for sf in (0.2, 1.0):
+        m = copy.deepcopy(models(sf)).to(DEV)
+        sd = models(sf).state_dict()
+        g = torch.Generator().manual_seed(64)
+        x = torch.randn(4, 3, 64, 64, generator=g)
+        t = torch.full((4,), 31, dtype=torch.long)
+        with torch.no_grad():
+            want = unet_ref.unet_forward(sd, x, t, torch.ones(4, 1))
+        got = m(x.to(DEV), t.to(DEV), torch.ones(4, 1, device=DEV))
+        h = engine.UNetHandle.for_module(m)
+        assert (4, 64, 64) in h._tuned
+        kinds = {(c[0], c[1]): c[5] for c in h.conv_choices(4, 64, 64)}
+        assert "strip" not in kinds[("enc1", "conv2")], kinds
+        _close(got.cpu().numpy(), want.numpy(), 1e-4, 2e-5, f"64x64 sf={sf}")
+
+
+def test_unchanged_caller_flow_with_aliases(models, tmp_path, monkeypatch):
+    """The flow of scripts/analysis/analyze_trajectory_metrics.py:458-505 with its OWN import lines (:22-26), made to
+    resolve to this package by install_aliases(): state_dict checkpoints on disk -> load_state_dict -> eval / to(device)
+    -> compare_trajectories per size factor -> transform_metrics per heat-map cell (:95-100)."""
+    import distillation_trajectories_amd as pkg
+    monkeypatch.chdir(tmp_path)
+    names = pkg.install_aliases()
+    try:
+        assert "config.config" in names and "analysis.trajectory_engine" in names
+        from config.config import Config as RefConfig                                # noqa: the reference's import lines
+        from models import DiffusionUNet as RefUNet
+        from analysis.trajectory_engine import compare_trajectories
+        from analysis.metrics.trajectory_metrics import compute_trajectory_metrics    # noqa: F401
+        from utils.metric_transformations import transform_metrics
+        config = RefConfig()
+        config.timesteps = 6
+        config.image_size = 16
+        # checkpoints as the training scripts leave them (scripts/train_teacher.py:86, train_students.py:185-187)
+        os.makedirs(config.teacher_models_dir)
+        torch.save(models(1.0).state_dict(), os.path.join(config.teacher_models_dir, "model_epoch_200.pt"))
+        size_factors = [0.2, 0.5]
+        for sf in size_factors:
+            d = os.path.join(config.student_models_dir, f"size_{sf}")
+            os.makedirs(d)
+            torch.save(models(0.01).state_dict(), os.path.join(d, "model_epoch_3.pt"))       # stale, wrong-size: never loaded
+            torch.save(models(sf).state_dict(), os.path.join(d, "model_epoch_12.pt"))   # "latest" = highest epoch
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        teacher_model = RefUNet(config, size_factor=1.0)
+        teacher_model.load_state_dict(torch.load(os.path.join(config.teacher_models_dir, "model_epoch_200.pt"), map_location=device))
+        teacher_model.eval()
+        teacher_model = teacher_model.to(device)
+        guidance_scales = [1.0, 3.0]
+        metrics_by_size = {}
+        for size_factor in size_factors:
+            size_dir = os.path.join(config.student_models_dir, f"size_{size_factor}")
+            model_files = [f for f in os.listdir(size_dir) if f.startswith("model_epoch_") and f.endswith(".pt")]
+            latest_model = max(model_files, key=lambda x: int(x.split("_")[2].split(".")[0]))
+            assert latest_model == "model_epoch_12.pt"
+            student_model = RefUNet(config, size_factor=size_factor)
+            student_model.load_state_dict(torch.load(os.path.join(size_dir, latest_model), map_location=device))
+            student_model = student_model.to(device)
+            student_model.eval()
+            metrics_by_size[size_factor] = compare_trajectories(teacher_model, student_model, config, guidance_scales=guidance_scales,
+                                                                size_factor=size_factor, num_samples=2)
+        # oracle on the same checkpoints
+        t_sd = models(1.0).state_dict()
+        for sf in size_factors:
+            s_sd = models(sf).state_dict()
+            with torch.no_grad():
+                ref = sampler_ref.compare_trajectories(lambda x, t, c: unet_ref.unet_forward(t_sd, x, t, c),
+                                                       lambda x, t, c, s_sd=s_sd: unet_ref.unet_forward(s_sd, x, t, c),
+                                                       config, guidance_scales=guidance_scales, num_samples=2)
+            for gs in guidance_scales:
+                got, want = metrics_by_size[sf]["student_metrics"][gs], ref["student_metrics"][gs]
+                _check_metric_dict({k: got[k] for k in want}, {k: float(v) for k, v in want.items()}, 1e-4, f"caller flow sf={sf} gs={gs}")
+                cell = transform_metrics(got["path_length_similarity"], got["trajectory_mse"], got["mean_directional_consistency"],
+                                         got["distribution_similarity"])
+                assert set(cell) == {"path_length_similarity", "trajectory_mse", "mean_directional_consistency", "distribution_similarity"}
+    finally:
+        pkg.remove_aliases()

@@ -215,3 +215,56 @@ def test_fid_sampler_and_formula(golden, models):
     assert np.array_equal(got.numpy(), arrays["fid_loop"])
     assert _close(metrics_ref.calculate_fid(arrays["fid_feat1"], arrays["fid_feat2"]), c["fid"], 1e-12)
     assert metrics_ref.calculate_fid(arrays["fid_feat1"][:1], arrays["fid_feat2"]) == c["fid_too_few"] == 999.0
+
+
+# ------------------------------------------------------------------ round-2 vectors: real model sizes
+def test_r02_same_weights_as_reference(golden_r02, models):
+    _, meta = golden_r02
+    for sf, digest in meta["state_dict_sha256"].items():
+        assert state_dict_digest(models(float(sf)).state_dict()) == digest
+
+
+def test_r02_unet_forward_all_size_factors_bit_exact(golden_r02, models):
+    arrays, meta = golden_r02
+    for c in meta["forward_cases"]:
+        x = seeded_noise(c["seed"], (c["b"], 3, c["h"], c["h"]))
+        t = torch.full((c["b"],), c["t"], dtype=torch.long)
+        with torch.no_grad():
+            y = eps_fn(models(c["sf"]))(x, t, cond_of(c["cond"], c["b"]))
+        assert np.array_equal(y.numpy(), arrays[c["key"]]), c
+
+
+def test_r02_config0_teacher_loop_bit_exact(golden_r02, models):
+    """configs[0]: teacher p_sample_loop, B=8, T=50, two passes per step (utils/diffusion.py:160-212)."""
+    arrays, meta = golden_r02
+    c = meta["config0_case"]
+    torch.manual_seed(c["global_seed"])
+    with torch.no_grad():
+        _, tr = sampler_ref.p_sample_loop(eps_fn(models(c["sf"])), (c["b"], 3, 16, 16), c["sample_steps"],
+                                          sampler_ref.diffusion_params(c["sample_steps"]), c["timesteps"], c["w"])
+    assert np.array_equal(torch.stack(tr).numpy(), arrays[c["key"]])
+
+
+def test_r02_config4_tail_from_stored_state(golden_r02, models):
+    """configs[4]: the last 50 of 1000 steps at 32x32, w=7, restarted from the reference's state after 950 steps with
+    the noise the reference drew (global generator stream: x_T, then one z per step)."""
+    arrays, meta = golden_r02
+    c = meta["config4_case"]
+    assert c["finite"]
+    tail = arrays[c["key"]]
+    shape = (c["b"], 3, c["h"], c["h"])
+    torch.manual_seed(c["global_seed"])
+    torch.randn(shape)                                              # x_T
+    zs = [torch.randn(shape) for _ in range(c["sample_steps"] - 1)]  # steps i = 999..1 draw; i = 0 does not
+    params = sampler_ref.diffusion_params(c["sample_steps"])
+    fn = eps_fn(models(c["sf"]))
+    x = torch.from_numpy(tail[0])
+    idx = sampler_ref.psample_indices(c["sample_steps"], c["timesteps"])
+    with torch.no_grad():
+        for k in range(c["first_entry"], c["sample_steps"]):
+            i = idx[k]
+            x = sampler_ref.p_sample(fn, x, torch.full((c["b"],), i, dtype=torch.long), i, params, c["w"],
+                                     noise=zs[k] if i > 0 else None)
+            assert np.array_equal(x.numpy(), tail[k - c["first_entry"] + 1]), k
+            if k - c["first_entry"] >= 5:      # the oracle is the same torch code path: six steps pin it, the GPU test runs all
+                break
