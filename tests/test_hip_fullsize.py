@@ -316,7 +316,7 @@ def test_config2_full_size_sweep_grid(golden_r02, models):
         for gs in c["guidance_scales"]:
             want = c["result"]["student_metrics"][str(gs)]
             got = {k: grid[i][gs][k] for k in want}
-            assert set(want) == set(engine.SCALAR_KEYS)
+            assert set(want) == set(engine.SCALAR_KEYS) - {"path_alignment"}     # np.float32 in the reference: not averaged (:171-175)
             _check_metric_dict(got, want, 1e-4, f"grid cell sf={c['student_sf']} gs={gs}")
 
 

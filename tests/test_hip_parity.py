@@ -239,6 +239,7 @@ def test_sampler_graph_replay_is_bit_exact(gpu_models, monkeypatch):
         return traj
     plain = run(torch.empty(len(idx) + 1, B, E, device=DEV)).clone()
     monkeypatch.setenv("DT_GRAPH", "1")
+    torch.cuda.synchronize()              # the handle's workspace is shared: the plain run must be done before another stream uses it
     side = torch.cuda.Stream()
     traj = torch.empty(len(idx) + 1, B, E, device=DEV)
     with torch.cuda.stream(side):
