@@ -188,6 +188,20 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   write_b(0);
   __syncthreads();
 
+  // ABL == 9 (diagnostic build, tools/tap_phases.py): s_memtime stamps split every step into
+  //   [0] fragment reads + MFMA issue, [1] wait for the next tap's weight loads, [2] their LDS writes, [3] barrier wait
+  // summed per wave in scalar registers; the real kernel executes none of this.
+  unsigned long long ph[4] = {0, 0, 0, 0}, ts = 0;
+  auto stamp = [&](int seg) __attribute__((always_inline)) {
+    if (ABL != 9) return;
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (seg >= 0) ph[seg] += t - ts;
+    ts = t;
+  };
+  stamp(-1);
   // One step = one tap of one (KC-chunk) group.  TT is the tap as a compile-time constant: the nine taps of a main
   // chunk are unrolled, so shifts, mask bits and the whole walk bookkeeping fold away and only the chunk loop is
   // left as scalar control.
@@ -248,12 +262,16 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
         }
       }
     }
+    stamp(0);
+    if (ABL == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(1); }
     if (more && ABL != 2) write_b((step + 1) & 1);
+    stamp(2);
     if (last_tap && next_chunk && ABL != 5) {
       __syncthreads();                                             // every wave is done with this chunk's strip
       write_strip();
     }
     if (ABL != 1 || last_tap) __syncthreads();
+    stamp(3);
     ++step;
   };
 
@@ -274,6 +292,12 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     do_step(std::integral_constant<int, 4>{}, ch, true, true, ch + 1 < n_chunks, ADV_SKIP);
   const long long tl1 = p.ablate == 8 ? wall_clock64() : 0;
   conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
+  if (ABL == 9) {                          // per-wave phase sums (cycles) + step count into the unused split-K slab
+    if (lane == 0) {
+      unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.slab) + 8 * (4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + wave);
+      rec[0] = ph[0]; rec[1] = ph[1]; rec[2] = ph[2]; rec[3] = ph[3]; rec[4] = (unsigned long long)step;
+    }
+  }
   if (p.ablate == 8 && p.splits == 1) {   // (start, loop end, end, hw id) per workgroup into the unused split-K slab
     __syncthreads();
     if (tid == 0) {
@@ -312,6 +336,7 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
       case 5: conv_strip_bf16x6_kernel<128, 128, 5><<<grid, 256, lds, s>>>(p); break;
       case 6: conv_strip_bf16x6_kernel<128, 128, 6><<<grid, 256, lds, s>>>(p); break;
       case 8: conv_strip_bf16x6_kernel<128, 128, 0><<<grid, 256, lds, s>>>(p); break;
+      case 9: conv_strip_bf16x6_kernel<128, 128, 9><<<grid, 256, lds, s>>>(p); break;
       default: return DT_E_ARG;
     }
     DT_LAUNCH_CHECK();

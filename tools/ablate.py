@@ -17,6 +17,7 @@ ws = h.workspace(512, 16, 16)
 lib = _hip.load()
 layers = [(0, 2, "enc1.conv2"), (1, 2, "enc2.conv2"), (7, 1, "dec1.conv1"), (2, 1, "enc3.conv1")]
 PREC = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # 1: plain split-bf16 kernel, 3: strip kernel
+SPLIT = int(sys.argv[2]) if len(sys.argv) > 2 else 0         # 0: the usual per-layer splits, else this split everywhere
 NAMES = {1: ((0, "full"), (1, "no barrier"), (2, "no LDS fragment reads"), (3, "no MFMA"), (4, "no global loads"), (5, "no split VALU")),
          3: ((0, "full"), (1, "no per-tap barrier"), (2, "no weight staging"), (3, "no MFMA"), (4, "no fragment reads"), (5, "no strip re-staging"), (6, "cache-hot weight loads"))}
 for ab, name in ((0, "(warm-up pass)"),) + NAMES[PREC] + ((0, "full again"),):
@@ -24,7 +25,7 @@ for ab, name in ((0, "(warm-up pass)"),) + NAMES[PREC] + ((0, "full again"),):
     row = f"{name:28s}"
     for j, slot, lname in layers:
         ms, fl = ctypes.c_float(), ctypes.c_double()
-        sp = (3 if PREC == 1 else 2) if lname in ("dec1.conv1", "enc3.conv1") else 1
+        sp = SPLIT or ((3 if PREC == 1 else 2) if lname in ("dec1.conv1", "enc3.conv1") else 1)
         st = lib.dt_unet_time_conv(h.h, 512, 16, 16, j, slot, 128, 128, sp, PREC, 0, 10, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(),
                                    ctypes.byref(ms), ctypes.byref(fl))
         row += f" {lname} {ms.value*1e3:7.1f}us" if st == 0 else f" {lname} ERR{st}"
