@@ -54,7 +54,8 @@ const char *kClassName[KC_COUNT] = {
     "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
     "conv_gemm_bf16x6_kernel<64,64>",
     "conv_strip_bf16x6_kernel<128,128>", "conv_strip_bf16x6_kernel<128,64>", "conv_strip_bf16x6_kernel<64,128>",
-    "conv_strip_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "conv_strip_bf16x6_kernel<64,64>", "conv_strip_pipe_bf16x6_kernel<128,128>", "conv_strip_pipe_bf16x6_kernel<128,64>",
+    "conv_strip_pipe_bf16x6_kernel<64,128>", "conv_strip_pipe_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
@@ -229,13 +230,14 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   if (!choice) {   // untuned default per mode; the strip kernel wherever the full 3x3 walk runs (uniformly >= the plain one)
     c.prec = u->precision == DT_PREC_FP32 ? 0 : 1;
     if (c.prec == 1 && p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && strip_admissible(p.W, 64, 64, 1)) {
-      c.prec = 3;
+      c.prec = strip_pipe_admissible(p.W, c.bm ? c.bm : 64, c.bn ? c.bn : 64) ? 5 : 3;
       const int cc = p.cin_p >> 4;   // tap groups 3 / 9 become channel-chunk groups 4 / 8 where they divide
       c.splits = c.splits == 9 ? (cc % 8 == 0 ? 8 : (cc % 4 == 0 ? 4 : 1)) : (c.splits == 3 ? (cc % 4 == 0 ? 4 : (cc % 2 == 0 ? 2 : 1)) : 1);
     }
   }
   if (c.prec == 2) c.prec = 1;
   if (c.prec >= 3 && (p.tap_hi - p.tap_lo != 9 || !strip_admissible(p.W, 64, 64, 1))) c.prec = 1;   // full 3x3 walks of rows <= 63 px only
+  if (c.prec == 5 && !strip_pipe_admissible(p.W, c.bm ? c.bm : 128, c.bn ? c.bn : 128)) c.prec = 3;
   if (c.prec == 4 && (p.cin_p >> 4) % 2) c.prec = 3;                // two chunks per step need an even chunk count
   if (p.x3 || j == 0 || p.M > kSplitMaxRows) c.splits = 1;          // (enc1: no slab; its conv2 keeps the fused x3 epilogue)
   if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * (c.prec == 4 ? 2 : 1)) != 0)
@@ -261,7 +263,7 @@ bool concat_in_place(const dt_unet *u, int j, float *ws, const Plan &pl, int Bt,
   ConvParams c1, c2;
   if (!conv_slot(u, j, 1, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][1] : nullptr, c1)) return false;
   if (!conv_slot(u, j, 2, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][2] : nullptr, c2)) return false;
-  return c1.prec >= 3 && c1.prec <= 4 && c2.prec >= 3 && c2.prec <= 4 && c2.in2 != nullptr;
+  return c1.prec >= 3 && c1.prec <= 5 && c2.prec >= 3 && c2.prec <= 5 && c2.in2 != nullptr;
 }
 
 int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
@@ -526,7 +528,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       // Kernel families worth timing (the search is paid once per model and shape, so it is pruned to what the
       // per-layer tables show can win): exact-fp32 mode -> the fp32-MFMA kernel only; otherwise the strip kernel
       // for full 3x3 walks, the plain split-bf16 kernel for everything else, the LDS-DMA kernel where twins exist.
-      for (int prec = 0; prec <= 4; ++prec) {
+      for (int prec = 0; prec <= 5; ++prec) {
         if (h->precision == DT_PREC_FP32 ? prec != 0 : prec == 0) continue;
         if (prec == 2) continue;
         const bool strip_ok = full3x3 && strip_admissible(p.W, 64, 64, 1);   // some strip tile fits this row width
@@ -542,7 +544,8 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
             if ((prec >= 3 || !walk9) && (p.cin_p >> 4) % (sp * (prec == 4 ? 2 : 1))) continue;
             if (prec == 4 && fuse && (kw.cin_p >> 4) % 2) continue;
-            if (prec >= 3 && !strip_admissible(p.W, bm, bn, prec == 4 ? 2 : 1)) continue;   // LDS footprint of this tile
+            if (prec >= 3 && prec <= 4 && !strip_admissible(p.W, bm, bn, prec == 4 ? 2 : 1)) continue;   // LDS footprint of this tile
+            if (prec == 5 && !strip_pipe_admissible(p.W, bm, bn)) continue;
             if (sp > 1 && tiles * (sp / 2) >= 1024) continue;          // already >= 4 workgroups per CU without this split
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
@@ -660,7 +663,7 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
   if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H < 16 || W < 16 || H % 16 || W % 16 || batch_total < 1)
     return DT_E_ARG;
   if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return DT_E_ARG;
-  if (splits < 1 || splits > 9 || prec < 0 || prec > 4 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
+  if (splits < 1 || splits > 9 || prec < 0 || prec > 5 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
   if (splits == 5 || splits == 6 || splits == 7) return DT_E_ARG;
   if (prec == 2) return DT_E_ARG;
   if (h->blk[block].n_p % bn) return DT_E_ARG;

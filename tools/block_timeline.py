@@ -1,5 +1,6 @@
-"""Per-workgroup timeline of one strip-kernel launch (DT_ABLATE=8 records start / loop end / end / hw id per
-workgroup into the split-K slab): dispatch ramp, steady state, epilogue and tail against the event-timed launch."""
+"""Per-workgroup timeline of pipelined-strip-kernel launches (DT_ABLATE=8 records start / prologue end / loop end /
+end per workgroup into the split-K slab): prologue, main loop, epilogue and tail against the event-timed launch.
+Usage: block_timeline.py [sf=1.0] [batch_total=512]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,36 +9,43 @@ from distillation_trajectories_amd import _hip, engine
 from distillation_trajectories_amd.config import Config
 from distillation_trajectories_amd.models import DiffusionUNet
 from distillation_trajectories_amd.synthetic import make_model
+sf = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+Bt = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 cfg = Config(); cfg.image_size = 16
-m = make_model(DiffusionUNet, cfg, 1.0).to("cuda:0")
+m = make_model(DiffusionUNet, cfg, sf).to("cuda:0")
 h = engine.UNetHandle.for_module(m)
-x = torch.randn(256, 3, 16, 16, device="cuda:0")
+x = torch.randn(Bt // 2, 3, 16, 16, device="cuda:0")
 tb = h.time_bias([10, 10], [_hip.COND_NONE, _hip.COND_ONE])
-h.forward(x, tb, 2, 256, tune=False)
-ws = h.workspace(512, 16, 16)
+h.forward(x, tb, 2, Bt // 2, tune=False)
+ws = h.workspace(Bt, 16, 16)
 lib = _hip.load()
 off, cp, oh, ow = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-lib.dt_unet_debug_activation(h.h, 512, 16, 16, 8, ctypes.byref(off), ctypes.byref(cp), ctypes.byref(oh), ctypes.byref(ow))
-os.environ["DT_ABLATE"] = "8"
-for j, slot, name, grid in ((1, 2, "enc2.conv2", 512), (7, 1, "dec1.conv1 (s1)", 256), (0, 2, "enc1.conv2", 1024)):
-    ms, fl = ctypes.c_float(), ctypes.c_double()
-    st = lib.dt_unet_time_conv(h.h, 512, 16, 16, j, slot, 128, 128, 1, 3, 0, 5, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms), ctypes.byref(fl))
-    torch.cuda.synchronize()
-    rec = ws.view(torch.float32)[off.value: off.value + grid * 8].view(torch.int64).cpu().numpy().reshape(grid, 4)
-    t0 = rec[:, 0].min()
-    start, loop_end, end = (rec[:, 0] - t0) * 0.01, (rec[:, 1] - t0) * 0.01, (rec[:, 2] - t0) * 0.01    # us (100 MHz clock)
-    hw = rec[:, 3] & 0xffffffff
-    xcc = rec[:, 3] >> 32
-    cu = (hw >> 8) & 0xf; se = (hw >> 13) & 0x7   # gfx9 HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
-    key = xcc * 1000 + se * 100 + ((hw >> 12) & 1) * 16 + cu
-    per_cu = np.unique(key, return_counts=True)[1]
-    print(f"{name}: event-timed launch {ms.value*1e3:.1f} us, {grid} workgroups on {len(per_cu)} CUs "
-          f"(per CU: min {per_cu.min()} max {per_cu.max()})")
-    print(f"  start  : median {np.median(start):6.1f}  p95 {np.percentile(start,95):6.1f}  max {start.max():6.1f} us after the first")
-    print(f"  loop   : median {np.median(loop_end-start):6.1f}  min {np.min(loop_end-start):6.1f}  max {np.max(loop_end-start):6.1f} us")
-    print(f"  epilog : median {np.median(end-loop_end):6.1f}  max {np.max(end-loop_end):6.1f} us")
-    print(f"  last workgroup ends {end.max():6.1f} us after the first one started; median end {np.median(end):6.1f}", flush=True)
-    loop = loop_end - start
-    print("  loop time by XCD (median / max us):", "  ".join(f"{int(k)}: {np.median(loop[xcc == k]):.0f}/{loop[xcc == k].max():.0f}" for k in np.unique(xcc)))
-    order = np.arange(grid)
-    print("  loop time by block-id quarter (median):", "  ".join(f"{np.median(loop[(order >= a) & (order < a + grid // 4)]):.0f}" for a in range(0, grid, grid // 4)))
+lib.dt_unet_debug_activation(h.h, Bt, 16, 16, 8, ctypes.byref(off), ctypes.byref(cp), ctypes.byref(oh), ctypes.byref(ow))
+d = h.dims
+LAYERS = [(0, 2, "enc1.conv2", 16, d[0]), (1, 1, "enc2.conv1", 8, d[1]), (1, 2, "enc2.conv2", 8, d[1]), (2, 1, "enc3.conv1", 4, d[2]),
+          (3, 1, "enc4.conv1", 2, d[3]), (6, 1, "dec2.conv1", 4, d[1]), (7, 1, "dec1.conv1", 8, d[0]), (7, 2, "dec1.conv2", 8, d[0])]
+print(f"sf={sf} batch_total={Bt}; per workgroup, microseconds (100 MHz wall clock): median [min .. max]")
+for j, slot, name, hw, cout in LAYERS:
+    M = Bt * hw * hw
+    npad = (cout + 63) // 64 * 64
+    for bm, bn in ((128, 128), (64, 64)):
+        if npad % bn:
+            continue
+        grid = (M + bm - 1) // bm * (npad // bn)
+        os.environ["DT_ABLATE"] = "0"
+        ms0, fl = ctypes.c_float(), ctypes.c_double()
+        lib.dt_unet_time_conv(h.h, Bt, 16, 16, j, slot, bm, bn, 1, 5, 0, 5, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms0), ctypes.byref(fl))
+        os.environ["DT_ABLATE"] = "8"
+        ms = ctypes.c_float()
+        st = lib.dt_unet_time_conv(h.h, Bt, 16, 16, j, slot, bm, bn, 1, 5, 0, 5, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms), ctypes.byref(fl))
+        torch.cuda.synchronize()
+        if st != 0:
+            print(f"{name} {bm}x{bn}: status {st}")
+            continue
+        rec = ws.view(torch.float32)[off.value: off.value + grid * 8].view(torch.int64).cpu().numpy().reshape(grid, 4) * 0.01
+        t0 = rec[:, 0].min()
+        pro, loop, epi = rec[:, 1] - rec[:, 0], rec[:, 2] - rec[:, 1], rec[:, 3] - rec[:, 2]
+        f = lambda a: f"{np.median(a):6.1f} [{a.min():5.1f} .. {a.max():5.1f}]"
+        print(f"{name:11s} {bm:3d}x{bn:<3d} {grid:5d} WGs ({grid / 256:4.1f}/CU)  launch {ms0.value * 1e3:6.1f} us ({fl.value / ms0.value / 1e9:4.0f} TF/s) | prologue {f(pro)} | loop {f(loop)} | "
+              f"epilogue {f(epi)} | first start->last end {rec[:, 3].max() - t0:6.1f}, starts spread {rec[:, 0].max() - t0:5.1f}", flush=True)
+os.environ["DT_ABLATE"] = "0"

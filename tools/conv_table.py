@@ -26,8 +26,8 @@ ws = h.workspace(Bt, H, H)
 lib = _hip.load()
 names = engine.BLOCK_NAMES
 print(f"sf={sf} batch_total={Bt}: us (TF/s fp32-equivalent) per launch; prec/tile/splits")
-configs = [(p, bm, bn, sp) for p in (0, 1, 2) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 3, 4, 8, 9)]
-configs += [(pr, bm, bn, sp) for pr in (3, 4) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 4, 8)]
+configs = [(p, bm, bn, sp) for p in (0, 1) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 3, 4, 8, 9)]
+configs += [(pr, bm, bn, sp) for pr in (3, 4, 5) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 4, 8)]
 for j in range(8):
     for slot in range(3):
         best = []
@@ -43,10 +43,10 @@ for j in range(8):
         best.sort()
         line = f"{names[j]:10s} {('skip','conv1','conv2')[slot]:5s} GF={best[0][5]/1e9:6.2f} | "
         for ms, prec, bm, bn, sp, fl in best[:4]:
-            line += f"{('f32','b6','dma','strip','strip32')[prec]}/{bm}x{bn}/s{sp}: {ms*1e3:6.1f}us ({fl/ms/1e9:4.0f}) | "
-        for prec in (0, 1, 2, 3, 4):      # best of each arithmetic
+            line += f"{('f32','b6','dma','strip','strip32','pipe')[prec]}/{bm}x{bn}/s{sp}: {ms*1e3:6.1f}us ({fl/ms/1e9:4.0f}) | "
+        for prec in (0, 1, 3, 4, 5):      # best of each arithmetic
             cand = [b for b in best if b[1] == prec]
             if cand:
                 ms, _, bm, bn, sp, fl = cand[0]
-                line += f" {('f32','b6','dma','strip','strip32')[prec]}={fl/ms/1e9:4.0f}"
+                line += f" {('f32','b6','dma','strip','strip32','pipe')[prec]}={fl/ms/1e9:4.0f}"
         print(line, flush=True)
