@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
   constexpr int MI = BM / 64, NI = BN / 64;     // 32x32 MFMA tiles per wave in m / n
   constexpr int A_PER = BM / 64, B_PER = BN / 64;  // float4 staged per thread
   constexpr int STAGE = (BM + BN) * 16;         // floats per LDS stage
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr int LDS_FLOATS = 2 * STAGE > epilogue_stage_floats<BN>() ? 2 * STAGE : epilogue_stage_floats<BN>();
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
     __syncthreads();
   }
 
-  conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
+  conv_epilogue<MI, NI>(p, acc, lds, m0, n0, wm, wn, half, l31);
 }
 
 int launch_splitk_epilogue(const ConvParams &p, hipStream_t s);

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(64 * WM * WN, BM * BN > 128 * 128 ? 2 : 3) void con
     }
     if (ABL != 1) __syncthreads();
   }
-  conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
+  static_assert(2 * STAGE * sizeof(__bf16) >= epilogue_stage_floats<BN>() * sizeof(float), "epilogue stage");
+  conv_epilogue<MI, NI>(p, acc, reinterpret_cast<float *>(lds), m0, n0, wm, wn, half, l31);
 }
 
 int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s) {

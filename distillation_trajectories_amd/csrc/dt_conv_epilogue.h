@@ -29,133 +29,147 @@ __device__ inline void split8(const f32x4 lo, const f32x4 hi, bf16x8 &p1, bf16x8
   }
 }
 
-template <int MI, int NI>
-__device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI], int m0, int n0, int wm, int wn,
-                                     int half, int l31) {
-  // ---- split-K: park the raw partial sums; splitk_epilogue_kernel finishes the layer
-  if (p.splits > 1) {
-    float *slab = p.slab + (size_t)blockIdx.z * p.M * p.cout_p;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
-      if (n >= p.cout_p) continue;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int mb = m0 + wm * (MI * 32) + mi * 32 + 4 * half;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < p.M) slab[(size_t)m * p.cout_p + n] = acc[mi][ni][r];
-        }
-      }
-    }
-    return;
-  }
+// floats of LDS the staged epilogue needs for a BN-column tile: 64 rows (one 32-row accumulator tile of each
+// wave row) at a pitch of BN + 4 floats
+template <int BN>
+constexpr int epilogue_stage_floats() { return 64 * (BN + 4); }
 
-  // ---- epilogue: folded BN, ReLU, time bias, residual; one 128-B channel run per (register, half).
-  // Everything that depends on the output ROW only (time-bias row, residual / x3 / pool addresses) is worked out once
-  // per row, not once per element, and without per-element integer division: a 32-row accumulator tile starts at a
-  // wave-uniform row, so the quotient of its first row by m_per_tb (resp. H*W) is divided once and the other rows
-  // only compare their remainder (a 32-row run crosses at most one boundary when the divisor is >= 32).
-  int ncol[NI];
-  float sc[NI], sh[NI], b2[NI];
-  float4 w3[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    ncol[ni] = n0 + wn * (NI * 32) + ni * 32 + l31;
-    const bool ok = ncol[ni] < p.cout_p;
-    const int nn = ok ? ncol[ni] : 0;
-    sc[ni] = p.scale[nn]; sh[ni] = p.shift[nn];
-    b2[ni] = p.in2 ? p.bias2[nn] : 0.f;
-    w3[ni] = p.x3 ? *reinterpret_cast<const float4 *>(p.w3 + 4 * nn) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!ok) ncol[ni] = -1;
-  }
+// Epilogue of every convolution kernel, staged through LDS.
+//
+// The accumulator layout (lane = column, register = row) makes a direct epilogue store 4 bytes per lane, and the
+// side inputs (residual, time bias) load the same way: measured per-workgroup timelines (tools/block_timeline.py)
+// put such an epilogue at 14 us for a 128 x 128 tile on an idle chip and 28-35 us with a residual or the fused pool
+// (one exposed memory latency per accumulator register).  Here a 32-row accumulator tile of each wave row goes
+// through LDS once ([64][BN + 4] floats, conflict-free both ways) and comes back as float4 per lane with a whole
+// row segment per 32 lanes: every side input is one batched float4 load per unit, every store is 16 bytes per lane,
+// and the mode flags are tested per pass, not per element.
+//
+// `stage` is any LDS the kernel no longer needs (>= epilogue_stage_floats<BN>() floats); every wave of the
+// workgroup must call this (it contains barriers).  Modes: split-K slab store (raw sums), or
+//   v = in2 ? acc + bias2 : relu?(acc * scale + shift);  v += time bias row;  v += residual;  v += x3 skip;
+//   out = v;  pool_out = 2x2 max of v (32-row tiles hold whole row pairs for W <= 16).
+template <int MI, int NI>
+__device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI], float *stage, int m0, int n0, int wm, int wn,
+                                     int half, int l31) {
+  constexpr int BN = NI * 64, P = BN + 4, C4 = BN / 4, U = C4 / 4;   // U float4 units per thread and pass
+  const int tid = threadIdx.x;
   const int HW = p.H * p.W;
+  const bool slab_mode = p.splits > 1;
+  float *slab = slab_mode ? p.slab + (size_t)blockIdx.z * p.M * p.cout_p : nullptr;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int mt = m0 + wm * (MI * 32) + mi * 32;            // first row of this 32-row tile (wave-uniform)
-    const bool tb_fast = p.m_per_tb >= 32, hw_fast = HW >= 32;
-    const int tq = mt / p.m_per_tb, tr = mt - tq * p.m_per_tb;
-    const int iq = mt / HW, ir = mt - iq * HW;
-    // time bias: a 32-row tile sees at most two rows of the table (fast path): both are loaded once per column
-    float tb0[NI], tb1[NI];
-    const bool tb_two = p.tb && tb_fast;
+    __syncthreads();                                   // the main loop (or the previous pass) is done with this LDS
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      tb0[ni] = tb1[ni] = 0.f;
-      if (tb_two && ncol[ni] >= 0) {
-        const int last = (p.M - 1) / p.m_per_tb;                 // rows past M are never stored; keep the read in range
-        tb0[ni] = p.tb[(size_t)(tq < last ? tq : last) * p.tb_stride + ncol[ni]];
-        tb1[ni] = p.tb[(size_t)(tq + 1 < last ? tq + 1 : last) * p.tb_stride + ncol[ni]];
-      }
-    }
-    float vv[NI][16];
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int L = 4 * half + (r & 3) + 8 * (r >> 2);       // row inside the tile
-      const int m = mt + L;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) vv[ni][r] = 0.f;
-      if (m >= p.M) continue;
-      const size_t orow = (size_t)m * p.cout_p;
-      const float *tbrow = nullptr;
-      const bool tb_second = tr + L >= p.m_per_tb;
-      if (p.tb && !tb_fast) tbrow = p.tb + (size_t)(m / p.m_per_tb) * p.tb_stride;
-      float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-      if (p.x3) {
-        const float *xr = p.x3 + (size_t)m * p.x3_stride;
-        x0 = xr[0];
-        if (p.x3_c > 1) x1 = xr[p.x3_step];
-        if (p.x3_c > 2) x2 = xr[2 * p.x3_step];
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int n = ncol[ni];
-        if (n < 0) continue;
-        float v;
-        if (p.in2) {
-          v = acc[mi][ni][r] + b2[ni];            // BN/ReLU were applied in registers before the skip walk
-        } else {
-          v = acc[mi][ni][r] * sc[ni] + sh[ni];
-          if (p.relu) v = fmaxf(v, 0.f);
-        }
-        if (tb_two) v += tb_second ? tb1[ni] : tb0[ni];
-        else if (tbrow) v += tbrow[n];
-        if (p.add) v += p.add[orow + n];
-        if (p.x3) {
-          float rs = w3[ni].w;
-          rs = fmaf(x0, w3[ni].x, rs);
-          if (p.x3_c > 1) rs = fmaf(x1, w3[ni].y, rs);
-          if (p.x3_c > 2) rs = fmaf(x2, w3[ni].z, rs);
-          v += rs;
-        }
-        p.out[orow + n] = v;
-        vv[ni][r] = v;
-      }
-    }
-    if (p.pool_out) {
-      // Register r holds tile row (r&3) + 8*(r>>2) + 4*half.  A 32-row tile starts on an even picture row, so for
-      // W = 16 the window of even column c is registers {r, r+1, r+8, r+9}, for W = 8 it is {r, r+1, r+4, r+5}.
-      const int Wo = p.W >> 1, wsh = p.W == 16 ? 4 : 3;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r16 = (q & 1) * 2 + (q >> 1) * 4, r8 = (q & 1) * 2 + (q >> 1) * 8;
-        const int r = p.W == 16 ? r16 : r8;
+      for (int r = 0; r < 16; ++r) {
         const int L = 4 * half + (r & 3) + 8 * (r >> 2);
-        const int m = mt + L;
-        if (m >= p.M) continue;
-        int b, rem;
-        if (hw_fast) { const bool over = ir + L >= HW; b = iq + (over ? 1 : 0); rem = ir + L - (over ? HW : 0); }
-        else { b = m / HW; rem = m - b * HW; }
-        const int y = rem >> wsh, x = rem & (p.W - 1);        // W is 8 or 16 here
-        const size_t mo = (((size_t)b * (p.H >> 1) + (y >> 1)) * Wo + (x >> 1)) * p.cout_p;
+        stage[(wm * 32 + L) * P + wn * (NI * 32) + ni * 32 + l31] = acc[mi][ni][r];
+      }
+    __syncthreads();
+    // ---- this thread's units: row = tid / C4 + k * (256 / C4), four consecutive channels
+    const int c4 = tid % C4, row0 = tid / C4;
+    const int n = n0 + c4 * 4;
+    const bool n_ok = n < p.cout_p;
+    f32x4 v[U];
+    int mrow[U];
+    bool ok[U];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          if (ncol[ni] < 0) continue;
-          const float mx = p.W == 16 ? fmaxf(fmaxf(vv[ni][r16], vv[ni][r16 + 1]), fmaxf(vv[ni][r16 + 8], vv[ni][r16 + 9]))
-                                     : fmaxf(fmaxf(vv[ni][r8], vv[ni][r8 + 1]), fmaxf(vv[ni][r8 + 4], vv[ni][r8 + 5]));
-          p.pool_out[mo + ncol[ni]] = mx;
+    for (int k = 0; k < U; ++k) {
+      const int row = row0 + k * (256 / C4);
+      mrow[k] = m0 + (row >> 5) * (MI * 32) + mi * 32 + (row & 31);
+      ok[k] = n_ok && mrow[k] < p.M;
+      v[k] = *reinterpret_cast<const f32x4 *>(stage + row * P + c4 * 4);
+    }
+    if (slab_mode) {
+#pragma unroll
+      for (int k = 0; k < U; ++k)
+        if (ok[k]) *reinterpret_cast<f32x4 *>(slab + (size_t)mrow[k] * p.cout_p + n) = v[k];
+      continue;
+    }
+    const int nn = n_ok ? n : 0;
+    if (p.in2) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4 *>(p.bias2 + nn);   // BN/ReLU were applied before the skip walk
+#pragma unroll
+      for (int k = 0; k < U; ++k) v[k] += b2;
+    } else {
+      const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + nn), sh = *reinterpret_cast<const f32x4 *>(p.shift + nn);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        v[k] = v[k] * sc + sh;
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[k][e] = fmaxf(v[k][e], 0.f);
         }
+      }
+    }
+    if (p.tb) {
+      f32x4 t[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        t[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[k]) t[k] = *reinterpret_cast<const f32x4 *>(p.tb + (size_t)(mrow[k] / p.m_per_tb) * p.tb_stride + n);
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) v[k] += t[k];
+    }
+    if (p.add) {
+      f32x4 a[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        a[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[k]) a[k] = *reinterpret_cast<const f32x4 *>(p.add + (size_t)mrow[k] * p.cout_p + n);
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) v[k] += a[k];
+    }
+    if (p.x3) {
+      // enc1's 1x1 skip of the <= 3-channel image, recomputed from the patches' centre taps
+      f32x4 w3[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w3[e] = *reinterpret_cast<const f32x4 *>(p.w3 + 4 * (nn + e));
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        if (!ok[k]) continue;
+        const float *xr = p.x3 + (size_t)mrow[k] * p.x3_stride;
+        const float x0 = xr[0], x1 = p.x3_c > 1 ? xr[p.x3_step] : 0.f, x2 = p.x3_c > 2 ? xr[2 * p.x3_step] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float rs = w3[e][3];
+          rs = fmaf(x0, w3[e][0], rs);
+          if (p.x3_c > 1) rs = fmaf(x1, w3[e][1], rs);
+          if (p.x3_c > 2) rs = fmaf(x2, w3[e][2], rs);
+          v[k][e] += rs;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (ok[k]) *reinterpret_cast<f32x4 *>(p.out + (size_t)mrow[k] * p.cout_p + n) = v[k];
+    if (p.pool_out) {
+      // final values back into the stage (each unit is this thread's own), then 2x2 windows: a 32-row tile starts on
+      // an even picture row and holds whole row pairs (W <= 16), eight pooled pixels per tile
+#pragma unroll
+      for (int k = 0; k < U; ++k) *reinterpret_cast<f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4) = v[k];
+      __syncthreads();
+      const int Wo = p.W >> 1;
+#pragma unroll
+      for (int q = tid; q < 16 * C4; q += 256) {
+        const int pp = q / C4, qc = q % C4, j = pp & 7;
+        const int yy = j / Wo, xx = j - yy * Wo;
+        const int L0 = 2 * yy * p.W + 2 * xx;
+        const int m = m0 + (pp >> 3) * (MI * 32) + mi * 32 + L0;
+        const int qn = n0 + qc * 4;
+        if (m >= p.M || qn >= p.cout_p) continue;
+        const float *s0 = stage + ((pp >> 3) * 32 + L0) * P + qc * 4;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(s0), b = *reinterpret_cast<const f32x4 *>(s0 + P);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(s0 + p.W * P), d = *reinterpret_cast<const f32x4 *>(s0 + (p.W + 1) * P);
+        f32x4 mx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+        const int bimg = m / HW, rem = m - bimg * HW;
+        const int y = rem / p.W, x = rem - y * p.W;
+        *reinterpret_cast<f32x4 *>(p.pool_out + (((size_t)bimg * (p.H >> 1) + (y >> 1)) * Wo + (x >> 1)) * p.cout_p + qn) = mx;
       }
     }
   }

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   for (int ch = n_main; ch < n_chunks; ++ch)                       // fused 1x1 skip walk: centre tap only
     do_step(std::integral_constant<int, 4>{}, ch, true, true, ch + 1 < n_chunks, ADV_SKIP);
   const long long tl1 = p.ablate == 8 ? wall_clock64() : 0;
-  conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
+  conv_epilogue<MI, NI>(p, acc, reinterpret_cast<float *>(strip_lds), m0, n0, wm, wn, half, l31);
   if (ABL == 9) {                          // per-wave phase sums (cycles) + step count into the unused split-K slab
     if (lane == 0) {
       unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.slab) + 8 * (4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + wave);
@@ -313,7 +313,9 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
 
 static size_t strip_lds_bytes(int W, int bm, int bn, int kc) {
   const int R = bm + 2 * (W + 1);
-  return (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 16) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
+  const size_t loop = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 16) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
+  const size_t stage = (size_t)64 * (bn + 4) * sizeof(float);      // the staged epilogue reuses the same LDS
+  return loop > stage ? loop : stage;
 }
 
 bool strip_admissible(int W, int bm, int bn, int kc) {

@@ -274,7 +274,16 @@ __global__ __launch_bounds__(256, 2) void conv_strip_pipe_bf16x6_kernel(const Co
     stamp(3);
   };
 
+  // Two workgroups share a CU (and each SIMD) on the big layers, and the SIMD's arbiter favours the older wave: left
+  // alone, the older workgroup finishes its loop 25 % before the younger one, which then runs the rest by itself at
+  // one wave per SIMD.  Blocks b and b + 256 are the pair that usually shares a CU (round-robin dispatch; a guess that
+  // only affects speed): they take the high priority in alternate chunks.
+  const int prio_grp = p.ablate == 7 ? 0 : ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1;
   for (int ch = 0; ch < n_main; ++ch) {
+    if (p.ablate != 7) {
+      if ((ch ^ prio_grp) & 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     const __bf16 *Acur = As + (ch & 1) * STRIP;
     __bf16 *Anext = As + ((ch + 1) & 1) * STRIP;
     read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, Acur, Bs);   // the one exposed read per chunk
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_strip_pipe_bf16x6_kernel(const Co
     do_tap(std::integral_constant<int, 8>{}, ch, Acur, Anext);
     wchunk += chunk_stride;
   }
+  __builtin_amdgcn_s_setprio(0);
   if (has_skip) {
     // fused 1x1 skip walk: centre tap only, one 16-channel chunk of in2 per step; skip chunk k sits in strip buffer
     // (n_main + k) & 1 and ring slot k % 3 (chunks 0, 1 were published by the last two main taps)
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv_strip_pipe_bf16x6_kernel(const Co
     }
   }
   const long long tl2 = p.ablate == 8 ? wall_clock64() : 0;
-  conv_epilogue<MI, NI>(p, acc, m0, n0, wm, wn, half, l31);
+  conv_epilogue<MI, NI>(p, acc, reinterpret_cast<float *>(pipe_lds), m0, n0, wm, wn, half, l31);
   if (p.ablate == 8 && p.splits == 1) {   // (start, prologue end, loop end, end) per workgroup into the unused split-K slab
     __syncthreads();
     if (tid == 0) {

@@ -243,8 +243,9 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * (c.prec == 4 ? 2 : 1)) != 0)
                   : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
-  // encoder blocks enc1..enc4 feed a 2x2 max pool: folded into this launch's epilogue where the windows are in-lane
-  if (slot == 2 && j <= 3 && c.splits == 1 && (w == 8 || w == 16) && h % 2 == 0) p.pool_out = ws + pl.pool[j];
+  // encoder blocks enc1..enc4 feed a 2x2 max pool: folded into this launch's staged epilogue where a 32-row tile holds
+  // whole row pairs (W a power of two <= 16)
+  if (slot == 2 && j <= 3 && c.splits == 1 && w >= 2 && w <= 16 && (w & (w - 1)) == 0 && h % 2 == 0) p.pool_out = ws + pl.pool[j];
   if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
   if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0 && !(c.prec == 4 && (k.cin_p >> 4) % 2)) {
     // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
