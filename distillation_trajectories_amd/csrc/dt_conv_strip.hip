@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   // One step = one tap of one (KC-chunk) group.  TT is the tap as a compile-time constant: the nine taps of a main
   // chunk are unrolled, so shifts, mask bits and the whole walk bookkeeping fold away and only the chunk loop is
   // left as scalar control.
+  const long long tl_pro = p.ablate == 8 ? wall_clock64() : 0;
   int step = 0;
   auto do_step = [&](auto TT, int ch, bool first_tap, bool last_tap, bool next_chunk, int adv) __attribute__((always_inline)) {
     constexpr int tt = decltype(TT)::value;
@@ -275,7 +276,19 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     ++step;
   };
 
+  // Two workgroups share a CU (and each SIMD) on the big layers, and the SIMD's arbiter favours the older wave: left
+  // alone, the older workgroup finishes its loop well before the younger one, which then runs the rest by itself at one
+  // wave per SIMD.  Blocks b and b + 256 are the pair that usually shares a CU (round-robin dispatch; a guess that only
+  // affects speed): they take the high priority in alternate chunk groups.
+  // (Only for grids of at most two workgroups per CU: with three resident ones two would share a priority -- measured
+  // 11 % slower on enc1.conv2's 1024 workgroups -- and larger grids refill CUs at arbitrary times anyway.)
+  const int prio_grp = ((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1;
+  const bool use_prio = p.ablate != 7 && gridDim.x * gridDim.y * gridDim.z <= 512;
   for (int ch = 0; ch < n_main; ++ch) {                            // 3x3 walk: nine unrolled taps per chunk group
+    if (use_prio) {
+      if ((ch ^ prio_grp) & 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     const bool next_chunk = ch + 1 < n_chunks;
     do_step(std::integral_constant<int, 0>{}, ch, true, false, next_chunk, ADV_TAP);
     do_step(std::integral_constant<int, 1>{}, ch, false, false, next_chunk, ADV_TAP);
@@ -288,6 +301,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     do_step(std::integral_constant<int, 8>{}, ch, false, true, next_chunk, ch + 1 < n_main ? ADV_GROUP : ADV_SKIP0);
     if (ch + 1 == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
   }
+  __builtin_amdgcn_s_setprio(0);
   for (int ch = n_main; ch < n_chunks; ++ch)                       // fused 1x1 skip walk: centre tap only
     do_step(std::integral_constant<int, 4>{}, ch, true, true, ch + 1 < n_chunks, ADV_SKIP);
   const long long tl1 = p.ablate == 8 ? wall_clock64() : 0;
@@ -298,15 +312,11 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
       rec[0] = ph[0]; rec[1] = ph[1]; rec[2] = ph[2]; rec[3] = ph[3]; rec[4] = (unsigned long long)step;
     }
   }
-  if (p.ablate == 8 && p.splits == 1) {   // (start, loop end, end, hw id) per workgroup into the unused split-K slab
+  if (p.ablate == 8 && p.splits == 1) {   // (start, prologue end, loop end, end) per workgroup into the unused split-K slab
     __syncthreads();
     if (tid == 0) {
-      unsigned hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      unsigned xcc;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      long long *rec = reinterpret_cast<long long *>(p.slab) + 4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
-      rec[0] = tl0; rec[1] = tl1; rec[2] = wall_clock64(); rec[3] = ((long long)xcc << 32) | hw;
+      long long *rec = reinterpret_cast<long long *>(p.slab) + 4 * (blockIdx.x + gridDim.x * blockIdx.y);
+      rec[0] = tl0; rec[1] = tl_pro; rec[2] = tl1; rec[3] = wall_clock64();
     }
   }
 }
@@ -329,7 +339,7 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
   if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 strip items per thread cover BM + 2(W+1) <= 256 rows
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   const size_t lds = strip_lds_bytes(p.W, bm, bn, kc);
-  if (p.ablate && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
+  if (p.ablate && p.ablate != 7 && p.ablate != 8 && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
     switch (p.ablate) {
       case 1: conv_strip_bf16x6_kernel<128, 128, 1><<<grid, 256, lds, s>>>(p); break;
       case 2: conv_strip_bf16x6_kernel<128, 128, 2><<<grid, 256, lds, s>>>(p); break;
@@ -337,7 +347,6 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
       case 4: conv_strip_bf16x6_kernel<128, 128, 4><<<grid, 256, lds, s>>>(p); break;
       case 5: conv_strip_bf16x6_kernel<128, 128, 5><<<grid, 256, lds, s>>>(p); break;
       case 6: conv_strip_bf16x6_kernel<128, 128, 6><<<grid, 256, lds, s>>>(p); break;
-      case 8: conv_strip_bf16x6_kernel<128, 128, 0><<<grid, 256, lds, s>>>(p); break;
       case 9: conv_strip_bf16x6_kernel<128, 128, 9><<<grid, 256, lds, s>>>(p); break;
       default: return DT_E_ARG;
     }

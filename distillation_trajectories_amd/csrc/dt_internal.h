@@ -25,7 +25,6 @@ enum KernelClass {
   KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
   KC_CONVB_128x128, KC_CONVB_128x64, KC_CONVB_64x128, KC_CONVB_64x64,
   KC_CONVS_128x128, KC_CONVS_128x64, KC_CONVS_64x128, KC_CONVS_64x64,
-  KC_CONVP_128x128, KC_CONVP_128x64, KC_CONVP_64x128, KC_CONVP_64x64,
   KC_SPLITK_EPILOGUE, KC_IM2COL, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
   KC_WASSERSTEIN, KC_RESAMPLE,
   KC_COUNT
@@ -69,8 +68,7 @@ struct ConvParams {
   int bm, bn;          // tile override (0 = pick by heuristic); bn = 128 needs n_p % 128 == 0
   int prec;            // 0: exact fp32 MFMA (w = fp32 pack), 1: split-bf16 (w = bf16x3 pack), 2: unused,
                        // 3: split-bf16 strip kernel (3x3 only; `splits` then divides the channel chunks, not the taps),
-                       // 4: strip kernel with two channel chunks (K = 32) per step,
-                       // 5: software-pipelined strip kernel (dt_conv_strip_pipe.hip)
+                       // 4: strip kernel with two channel chunks (K = 32) per step
   // enc1's 1x1 skip of the C<=4 channel image, recomputed in the epilogue instead of being
   // materialised: add = sum_c x3[m*x3_stride + c*x3_step] * w3[n*4+c] + w3[n*4+3]
   const float *x3;
@@ -100,8 +98,6 @@ int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s);
 int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s);   // prec 3 (kc 1) / 4 (kc 2): 3x3 only
 // whether the strip kernel can run a bm x bn tile with kc chunks per step on rows of W pixels (staging reach, LDS)
 bool strip_admissible(int W, int bm, int bn, int kc);
-int launch_conv_strip_pipe(const ConvParams &p, int bm, int bn, hipStream_t s);      // prec 5
-bool strip_pipe_admissible(int W, int bm, int bn);
 int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int n_p,
                             int split_c, int split_cp, hipStream_t s);
 struct ConvChoice { int bm, bn, splits, prec, fuse; };

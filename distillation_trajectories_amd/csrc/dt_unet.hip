@@ -7,6 +7,7 @@
 //   up+cat(enc4) -> dec3 @H/8 -> up+cat(enc3) -> dec2 @H/4 -> up+cat(enc2) -> dec1 @H/2 -> up + 1x1 head @H
 // Each residual block is up to three implicit-GEMM launches (1x1 skip, conv1, conv2) whose epilogues
 // carry BN/ReLU/time-bias/residual, so a forward is 8 blocks * (2..3) + 4 pools + 3 upcats + 2 = ~32 launches.
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -54,8 +55,7 @@ const char *kClassName[KC_COUNT] = {
     "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
     "conv_gemm_bf16x6_kernel<64,64>",
     "conv_strip_bf16x6_kernel<128,128>", "conv_strip_bf16x6_kernel<128,64>", "conv_strip_bf16x6_kernel<64,128>",
-    "conv_strip_bf16x6_kernel<64,64>", "conv_strip_pipe_bf16x6_kernel<128,128>", "conv_strip_pipe_bf16x6_kernel<128,64>",
-    "conv_strip_pipe_bf16x6_kernel<64,128>", "conv_strip_pipe_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "conv_strip_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
@@ -230,14 +230,13 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   if (!choice) {   // untuned default per mode; the strip kernel wherever the full 3x3 walk runs (uniformly >= the plain one)
     c.prec = u->precision == DT_PREC_FP32 ? 0 : 1;
     if (c.prec == 1 && p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && strip_admissible(p.W, 64, 64, 1)) {
-      c.prec = strip_pipe_admissible(p.W, c.bm ? c.bm : 64, c.bn ? c.bn : 64) ? 5 : 3;
+      c.prec = 3;
       const int cc = p.cin_p >> 4;   // tap groups 3 / 9 become channel-chunk groups 4 / 8 where they divide
       c.splits = c.splits == 9 ? (cc % 8 == 0 ? 8 : (cc % 4 == 0 ? 4 : 1)) : (c.splits == 3 ? (cc % 4 == 0 ? 4 : (cc % 2 == 0 ? 2 : 1)) : 1);
     }
   }
   if (c.prec == 2) c.prec = 1;
   if (c.prec >= 3 && (p.tap_hi - p.tap_lo != 9 || !strip_admissible(p.W, 64, 64, 1))) c.prec = 1;   // full 3x3 walks of rows <= 63 px only
-  if (c.prec == 5 && !strip_pipe_admissible(p.W, c.bm ? c.bm : 128, c.bn ? c.bn : 128)) c.prec = 3;
   if (c.prec == 4 && (p.cin_p >> 4) % 2) c.prec = 3;                // two chunks per step need an even chunk count
   if (p.x3 || j == 0 || p.M > kSplitMaxRows) c.splits = 1;          // (enc1: no slab; its conv2 keeps the fused x3 epilogue)
   if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * (c.prec == 4 ? 2 : 1)) != 0)
@@ -264,7 +263,7 @@ bool concat_in_place(const dt_unet *u, int j, float *ws, const Plan &pl, int Bt,
   ConvParams c1, c2;
   if (!conv_slot(u, j, 1, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][1] : nullptr, c1)) return false;
   if (!conv_slot(u, j, 2, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][2] : nullptr, c2)) return false;
-  return c1.prec >= 3 && c1.prec <= 5 && c2.prec >= 3 && c2.prec <= 5 && c2.in2 != nullptr;
+  return c1.prec >= 3 && c1.prec <= 4 && c2.prec >= 3 && c2.prec <= 4 && c2.in2 != nullptr;
 }
 
 int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
@@ -526,12 +525,39 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       const bool can_fuse = slot == 2 && j > 0 && h->blk[j].has_res;
       const BlockW &kw = h->blk[j];
       const bool full3x3 = p.ksize == 3 && p.tap_hi - p.tap_lo == 9;
+      // average milliseconds of `reps` back-to-back launches of one candidate (one warm launch first): in the sampler
+      // launches queue behind each other, so a candidate is not charged the idle-queue launch latency per kernel
+      // (which would bias against split launches = two kernels); < 0: not admissible here
+      auto measure = [&](const ConvParams &q, int reps) -> float {
+        int lst = launch_conv(q, s);
+        if (lst == DT_E_SHAPE || lst == DT_E_ARG) return -1.f;
+        if (lst != DT_OK) { st = lst; return -1.f; }
+        (void)hipEventRecord(e0, s);
+        for (int rep = 0; rep < reps && lst == DT_OK; ++rep) lst = launch_conv(q, s);
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) lst = (int)hipGetLastError();
+        if (lst != DT_OK) { st = lst; return -1.f; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        return ms / reps;
+      };
+      struct Cand { ConvChoice c; ConvParams q; float cost; };
+      std::vector<Cand> cands;
+      static const float split_margin = getenv("DT_TUNE_SPLIT_MARGIN") ? (float)atof(getenv("DT_TUNE_SPLIT_MARGIN")) : 1.05f;
+      // a fused conv2 also saves the separate skip launch measured for slot 0; launches are timed on an otherwise idle
+      // GPU, where extra workgroups are free, whereas in the sampler other streams fill idle CUs: a split (slab traffic
+      // + one more launch) must win by a margin to be taken
+      auto cost_of = [&](float ms, const ConvChoice &c) {
+        return (ms + (c.fuse ? 0.f : (can_fuse ? skip_ms : 0.f))) * (c.splits > 1 ? split_margin : 1.0f);
+      };
       // Kernel families worth timing (the search is paid once per model and shape, so it is pruned to what the
-      // per-layer tables show can win): exact-fp32 mode -> the fp32-MFMA kernel only; otherwise the strip kernel
-      // for full 3x3 walks, the plain split-bf16 kernel for everything else, the LDS-DMA kernel where twins exist.
-      for (int prec = 0; prec <= 5; ++prec) {
+      // per-layer tables show can win): exact-fp32 mode -> the fp32-MFMA kernel only; otherwise the strip kernels
+      // for full 3x3 walks and the plain split-bf16 kernel for everything else.
+      for (int prec = 0; prec <= 4 && st == DT_OK; ++prec) {
         if (h->precision == DT_PREC_FP32 ? prec != 0 : prec == 0) continue;
         if (prec == 2) continue;
+        static const int skip_mask = getenv("DT_TUNE_SKIP_PREC") ? atoi(getenv("DT_TUNE_SKIP_PREC")) : 0;   // experiments: bit p drops family p
+        if (skip_mask & (1 << prec)) continue;
         const bool strip_ok = full3x3 && strip_admissible(p.W, 64, 64, 1);   // some strip tile fits this row width
         if (prec >= 3 && !strip_ok) continue;
         if (prec == 4 && (p.cin_p >> 4) % 2) continue;
@@ -545,8 +571,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
             if ((prec >= 3 || !walk9) && (p.cin_p >> 4) % (sp * (prec == 4 ? 2 : 1))) continue;
             if (prec == 4 && fuse && (kw.cin_p >> 4) % 2) continue;
-            if (prec >= 3 && prec <= 4 && !strip_admissible(p.W, bm, bn, prec == 4 ? 2 : 1)) continue;   // LDS footprint of this tile
-            if (prec == 5 && !strip_pipe_admissible(p.W, bm, bn)) continue;
+            if (prec >= 3 && !strip_admissible(p.W, bm, bn, prec == 4 ? 2 : 1)) continue;   // LDS footprint of this tile
             if (sp > 1 && tiles * (sp / 2) >= 1024) continue;          // already >= 4 workgroups per CU without this split
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
@@ -555,28 +580,30 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
               q.add = nullptr; q.in2 = in; q.w2 = prec ? kw.wrb : kw.wr; q.bias2 = kw.hr; q.cin2_p = kw.cin_p;
               q.cin2_real = kw.cin;
             }
-            float ms_min = 1e30f;
-            bool admissible = true;
-            for (int rep = 0; rep < 4 && st == DT_OK; ++rep) {
-              (void)hipEventRecord(e0, s);
-              st = launch_conv(q, s);
-              if (st == DT_E_SHAPE || st == DT_E_ARG) { st = DT_OK; admissible = false; break; }   // not a candidate here
-              (void)hipEventRecord(e1, s);
-              if (hipEventSynchronize(e1) != hipSuccess) st = (int)hipGetLastError();
-              float ms = 0.f;
-              (void)hipEventElapsedTime(&ms, e0, e1);
-              if (rep > 0 && ms < ms_min) ms_min = ms;   // first repetition warms caches / code
-            }
-            // a fused conv2 also saves the separate skip launch measured for slot 0
-            // candidates are visited from small to large tiles: a later (larger-tile, fewer-workgroup) one wins
-            // ties within 2 % so that run-to-run timing noise does not flip the plan
-            // launches are timed on an idle GPU, where extra workgroups are free; in the sampler other streams fill
-            // idle CUs anyway, so a split (slab traffic + one more launch) must win by a margin to be taken
-            if (!admissible || ms_min >= 1e30f) continue;
-            static const float split_margin = getenv("DT_TUNE_SPLIT_MARGIN") ? (float)atof(getenv("DT_TUNE_SPLIT_MARGIN")) : 1.1f;
-            const float cost = (ms_min + (fuse ? 0.f : (can_fuse ? skip_ms : 0.f))) * (sp > 1 ? split_margin : 1.0f);
-            if (cost < best_ms * 1.02f) { best_ms = cost < best_ms ? cost : best_ms; best = ConvChoice{bm, bn, sp, prec, fuse}; }
+            const float ms = measure(q, 3);
+            if (ms < 0.f) continue;
+            const ConvChoice c{bm, bn, sp, prec, fuse};
+            cands.push_back(Cand{c, q, cost_of(ms, c)});
           }
+        }
+      }
+      // second look at the three cheapest: longer, interleaved runs (clock drift and timing noise otherwise flip
+      // choices between near-equal candidates from run to run); ties within 1 % go to the later (larger-tile) candidate
+      if (!cands.empty() && st == DT_OK) {
+        std::vector<size_t> top;
+        for (size_t i = 0; i < cands.size(); ++i) top.push_back(i);
+        std::stable_sort(top.begin(), top.end(), [&](size_t a, size_t b) { return cands[a].cost < cands[b].cost; });
+        if (top.size() > 3) top.resize(3);
+        std::sort(top.begin(), top.end());
+        std::vector<float> fin(top.size(), 1e30f);
+        for (int round = 0; round < 2 && st == DT_OK; ++round)
+          for (size_t k = 0; k < top.size() && st == DT_OK; ++k) {
+            const float ms = measure(cands[top[k]].q, 10);
+            if (ms >= 0.f && ms < fin[k]) fin[k] = ms;
+          }
+        for (size_t k = 0; k < top.size(); ++k) {
+          const float cost = cost_of(fin[k], cands[top[k]].c);
+          if (cost < best_ms * 1.01f) { best_ms = cost < best_ms ? cost : best_ms; best = cands[top[k]].c; }
         }
       }
       t.c[j][slot] = best;
@@ -664,7 +691,7 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
   if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H < 16 || W < 16 || H % 16 || W % 16 || batch_total < 1)
     return DT_E_ARG;
   if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return DT_E_ARG;
-  if (splits < 1 || splits > 9 || prec < 0 || prec > 5 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
+  if (splits < 1 || splits > 9 || prec < 0 || prec > 4 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
   if (splits == 5 || splits == 6 || splits == 7) return DT_E_ARG;
   if (prec == 2) return DT_E_ARG;
   if (h->blk[block].n_p % bn) return DT_E_ARG;

@@ -122,14 +122,13 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
 
 /* tuning / test hook: pin the launch choice of one convolution of a forward shape (the other slots keep
  * their current choice).  bm x bn in {64,128}^2;
- * prec 0..5 as reported by dt_unet_conv_choice; splits in {1,3,9} taps, or 1..8 channel-chunk groups for the
+ * prec 0..4 as reported by dt_unet_conv_choice; splits in {1,3,9} taps, or 1..8 channel-chunk groups for the
  * strip kernel (prec 3; reset to 1 where it does not divide); fuse only for slot 2. */
 int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn,
                             int splits, int prec, int fuse);
 
 /* tuning aid: time ONE convolution launch (block, slot) of a forward shape under an explicit choice
- * (prec: 0 fp32 MFMA, 1 split-bf16, 3 / 4 split-bf16 strip kernel with K = 16 / 32 per step, 5 the software-
- * pipelined strip kernel); averages `reps` launches with HIP events */
+ * (prec: 0 fp32 MFMA, 1 split-bf16, 3 / 4 split-bf16 strip kernel with K = 16 / 32 per step); averages `reps` launches with HIP events */
 int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn,
                       int splits, int prec, int fuse, int reps, void *workspace_dev, size_t workspace_bytes,
                       void *stream, float *ms, double *flops);

@@ -187,9 +187,7 @@ def test_conv_tile_variants_match_oracle(gpu_models):
                                            (1, 128, 64, 1, 1), (1, 64, 64, 1, 0), (0, 128, 64, 1, 1), (0, 64, 128, 9, 0),
                                            (1, 128, 128, 3, 0), (3, 128, 128, 1, 0), (3, 128, 64, 2, 0), (3, 64, 128, 4, 0),
                                            (3, 64, 64, 1, 1), (3, 128, 128, 1, 1), (1, 64, 64, 4, 0), (0, 64, 64, 2, 0), (1, 128, 64, 8, 0), (4, 128, 128, 1, 0), (4, 64, 64, 2, 0),
-                                           (4, 128, 64, 1, 1), (4, 64, 128, 4, 0),
-                                           (5, 128, 128, 1, 0), (5, 128, 128, 1, 1), (5, 128, 64, 2, 0), (5, 64, 128, 4, 0),
-                                           (5, 64, 64, 1, 1), (5, 64, 64, 8, 0), (5, 128, 64, 1, 1)]:
+                                           (4, 128, 64, 1, 1), (4, 64, 128, 4, 0)]:
                 h.set_precision(_hip.PREC_AUTO)       # back to the heuristic plan
                 try:
                     h.set_conv_choice(2 * B, 16, 16, block, slot, bm, bn, sp, prec, fuse if slot == 2 else 0)
@@ -215,7 +213,7 @@ def test_conv_tile_variants_match_oracle(gpu_models):
             assert_close(got[B:B + 3].cpu().numpy(), want, what=f"block {block} skip {prec}/{bm}x{bn}/s{sp}")
             skips += 1
     h.set_precision(_hip.PREC_AUTO)
-    assert tried >= 280 and skips >= 10
+    assert tried >= 210 and skips >= 10
 
 
 def test_sampler_graph_replay_is_bit_exact(gpu_models, monkeypatch):

@@ -1,4 +1,4 @@
-"""Per-workgroup timeline of pipelined-strip-kernel launches (DT_ABLATE=8 records start / prologue end / loop end /
+"""Per-workgroup timeline of strip-kernel launches (DT_ABLATE=8 records start / prologue end / loop end /
 end per workgroup into the split-K slab): prologue, main loop, epilogue and tail against the event-timed launch.
 Usage: block_timeline.py [sf=1.0] [batch_total=512]"""
 import ctypes, os, sys
@@ -11,6 +11,7 @@ from distillation_trajectories_amd.models import DiffusionUNet
 from distillation_trajectories_amd.synthetic import make_model
 sf = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 Bt = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+PREC = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # 3: strip kernel, 4: strip kernel with K = 32 per step
 cfg = Config(); cfg.image_size = 16
 m = make_model(DiffusionUNet, cfg, sf).to("cuda:0")
 h = engine.UNetHandle.for_module(m)
@@ -34,10 +35,10 @@ for j, slot, name, hw, cout in LAYERS:
         grid = (M + bm - 1) // bm * (npad // bn)
         os.environ["DT_ABLATE"] = "0"
         ms0, fl = ctypes.c_float(), ctypes.c_double()
-        lib.dt_unet_time_conv(h.h, Bt, 16, 16, j, slot, bm, bn, 1, 5, 0, 5, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms0), ctypes.byref(fl))
+        lib.dt_unet_time_conv(h.h, Bt, 16, 16, j, slot, bm, bn, 1, PREC, 0, 5, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms0), ctypes.byref(fl))
         os.environ["DT_ABLATE"] = "8"
         ms = ctypes.c_float()
-        st = lib.dt_unet_time_conv(h.h, Bt, 16, 16, j, slot, bm, bn, 1, 5, 0, 5, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms), ctypes.byref(fl))
+        st = lib.dt_unet_time_conv(h.h, Bt, 16, 16, j, slot, bm, bn, 1, PREC, 0, 5, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms), ctypes.byref(fl))
         torch.cuda.synchronize()
         if st != 0:
             print(f"{name} {bm}x{bn}: status {st}")

@@ -27,7 +27,7 @@ lib = _hip.load()
 names = engine.BLOCK_NAMES
 print(f"sf={sf} batch_total={Bt}: us (TF/s fp32-equivalent) per launch; prec/tile/splits")
 configs = [(p, bm, bn, sp) for p in (0, 1) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 3, 4, 8, 9)]
-configs += [(pr, bm, bn, sp) for pr in (3, 4, 5) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 4, 8)]
+configs += [(pr, bm, bn, sp) for pr in (3, 4) for (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64)) for sp in (1, 2, 4, 8)]
 for j in range(8):
     for slot in range(3):
         best = []
@@ -44,7 +44,7 @@ for j in range(8):
         line = f"{names[j]:10s} {('skip','conv1','conv2')[slot]:5s} GF={best[0][5]/1e9:6.2f} | "
         for ms, prec, bm, bn, sp, fl in best[:4]:
             line += f"{('f32','b6','dma','strip','strip32','pipe')[prec]}/{bm}x{bn}/s{sp}: {ms*1e3:6.1f}us ({fl/ms/1e9:4.0f}) | "
-        for prec in (0, 1, 3, 4, 5):      # best of each arithmetic
+        for prec in (0, 1, 3, 4):      # best of each arithmetic
             cand = [b for b in best if b[1] == prec]
             if cand:
                 ms, _, bm, bn, sp, fl = cand[0]

@@ -17,7 +17,7 @@ tb = h.time_bias([10, 10], [_hip.COND_NONE, _hip.COND_ONE])
 h.forward(x, tb, 2, 256, tune=False)
 ws = h.workspace(512, 16, 16)
 lib = _hip.load()
-PREC = int(sys.argv[1]) if len(sys.argv) > 1 else 3     # 3: strip kernel, 5: software-pipelined strip kernel
+PREC = int(sys.argv[1]) if len(sys.argv) > 1 else 3     # 3: strip kernel
 off, cp, oh, ow = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
 lib.dt_unet_debug_activation(h.h, 512, 16, 16, 8, ctypes.byref(off), ctypes.byref(cp), ctypes.byref(oh), ctypes.byref(ow))
 for j, slot, name, grid in ((7, 1, "dec1.conv1 (1 WG/CU)", 256), (1, 2, "enc2.conv2 (2 WG/CU)", 512), (0, 2, "enc1.conv2 (4 WG/CU)", 1024)):
