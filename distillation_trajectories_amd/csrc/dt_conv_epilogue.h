@@ -124,15 +124,16 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       for (int k = 0; k < U; ++k) v[k] += a[k];
     }
     if (p.x3) {
-      // enc1's 1x1 skip of the <= 3-channel image, recomputed from the patches' centre taps
+      // enc1's 1x1 skip of the <= 3-channel image, recomputed from the NCHW image itself
       f32x4 w3[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) w3[e] = *reinterpret_cast<const f32x4 *>(p.w3 + 4 * (nn + e));
 #pragma unroll
       for (int k = 0; k < U; ++k) {
         if (!ok[k]) continue;
-        const float *xr = p.x3 + (size_t)mrow[k] * p.x3_stride;
-        const float x0 = xr[0], x1 = p.x3_c > 1 ? xr[p.x3_step] : 0.f, x2 = p.x3_c > 2 ? xr[2 * p.x3_step] : 0.f;
+        const int img = mrow[k] / p.x3_hw, pix = mrow[k] - img * p.x3_hw;
+        const float *xr = p.x3 + (size_t)(img % p.x3_imgs) * p.x3_c * p.x3_hw + pix;
+        const float x0 = xr[0], x1 = p.x3_c > 1 ? xr[p.x3_hw] : 0.f, x2 = p.x3_c > 2 ? xr[2 * p.x3_hw] : 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float rs = w3[e][3];

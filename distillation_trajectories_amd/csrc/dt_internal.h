@@ -25,7 +25,7 @@ enum KernelClass {
   KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
   KC_CONVB_128x128, KC_CONVB_128x64, KC_CONVB_64x128, KC_CONVB_64x64,
   KC_CONVS_128x128, KC_CONVS_128x64, KC_CONVS_64x128, KC_CONVS_64x64,
-  KC_SPLITK_EPILOGUE, KC_IM2COL, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
+  KC_SPLITK_EPILOGUE, KC_FIRST_CONV, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
   KC_WASSERSTEIN, KC_RESAMPLE,
   KC_COUNT
 };
@@ -69,11 +69,11 @@ struct ConvParams {
   int prec;            // 0: exact fp32 MFMA (w = fp32 pack), 1: split-bf16 (w = bf16x3 pack), 2: unused,
                        // 3: split-bf16 strip kernel (3x3 only; `splits` then divides the channel chunks, not the taps),
                        // 4: strip kernel with two channel chunks (K = 32) per step
-  // enc1's 1x1 skip of the C<=4 channel image, recomputed in the epilogue instead of being
-  // materialised: add = sum_c x3[m*x3_stride + c*x3_step] * w3[n*4+c] + w3[n*4+3]
+  // enc1's 1x1 skip of the C <= 3 channel image x[imgs][C][H*W] (NCHW, shared by all passes), recomputed in the
+  // epilogue instead of being materialised: add = sum_c x3[((m / hw) % imgs) * C * hw + c * hw + m % hw] * w3[n*4+c] + w3[n*4+3]
   const float *x3;
   const float *w3;
-  int x3_stride, x3_step, x3_c;
+  int x3_hw, x3_imgs, x3_c;
   // fused 1x1 skip (splits == 1 only): after the last chunk of the main K walk the accumulators become
   // relu(acc*scale+shift) IN REGISTERS, then the walk continues over in2[M][cin2_p] x w2 (the block's
   // residual_conv) on the same accumulators; the epilogue only adds bias2.  Saves the skip launch and the
@@ -111,7 +111,10 @@ int launch_fold_bn(const float *conv_b, const float *g, const float *b, const fl
 int launch_pack_linear_rows(const float *w, const float *b, float *wp, float *bp, int out, int in, int out_p,
                             hipStream_t s);
 
-int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, int W, int kp, hipStream_t s);
+// enc1.conv1 + BN + ReLU + time bias straight from the NCHW image (direct fp32 convolution, K = 9C <= 27)
+int launch_first_conv(const float *x, const float *wf, const float *scale, const float *shift, const float *tb, int tb_stride,
+                      int tb_div, float *out, int B, int n_pass, int C, int H, int W, int cout, int cout_p, hipStream_t s);
+int launch_pack_first_conv(const float *w_oihw, float *wf, int cout, int C, int cout_p, hipStream_t s);
 int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s);
 // skip == nullptr: only the upsampled channels are written (the consumers read the skip half in place)
 int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p,

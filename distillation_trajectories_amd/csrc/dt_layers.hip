@@ -6,40 +6,80 @@
 
 namespace dt {
 
-// First-layer im2col: x[B][C][H][W] (NCHW, shared by all passes) -> patches[n_pass*B*H*W][kp] with
-// k = c*9 + (ky*3+kx) (the flattened OIHW order of conv1.weight), zero padding at the image border and
-// for k >= 9C.  enc1.conv1 then runs as a 1x1 GEMM with K = kp instead of a 9-tap walk over a
-// 16-channel-padded image (K = 144), and the centre taps (k = 9c+4) double as the NHWC image.
-__global__ void im2col3_kernel(const float *__restrict__ x, float *__restrict__ out, int B, int n_pass, int C, int H,
-                               int W, int kp) {
-  // one thread per (pixel, 4 consecutive k): 32-bit index math, one float4 store
-  const unsigned kq = (unsigned)kp >> 2;
-  const unsigned total = (unsigned)n_pass * B * H * W * kq;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const unsigned q = i % kq;
-    unsigned pix = i / kq;
-    const int xx = pix % W; pix /= W;
-    const int yy = pix % H;
-    const unsigned b = (pix / H) % B;
-    const float *img = x + (size_t)b * C * H * W;
-    float v[4];
+// enc1.conv1 (reference models.py:61-63 on the C <= 3 channel image): conv3x3 + folded BN + ReLU + time bias as a
+// direct fp32 convolution.  K = 9C <= 27 is far too short for the matrix cores (the former im2col + K = 32 GEMM spent
+// 28 + 6 us per teacher forward on 0.1 GFLOP); here a thread keeps the 9C x 4 weights of its channel quad in registers,
+// the zero-bordered image sits in LDS, and the value is computed ONCE per image and stored for every pass with that
+// pass's time-bias row (the passes of a CFG step share x and differ only in the embedding).  HBM-bound on the store.
+template <int C>
+__global__ __launch_bounds__(256) void first_conv_kernel(const float *__restrict__ x, const float *__restrict__ wf,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift,
+                                                         const float *__restrict__ tb, int tb_stride, int tb_div,
+                                                         float *__restrict__ out, int B, int n_pass, int H, int W, int cp,
+                                                         int parts) {
+  extern __shared__ float img[];                       // [C][H+2][W+2], zero border
+  const int tid = threadIdx.x, b = blockIdx.x / parts, part = blockIdx.x - b * parts;
+  const int Wp = W + 2, plane = (H + 2) * Wp, HW = H * W;
+  for (int i = tid; i < C * plane; i += 256) {
+    const int c = i / plane, r = i - c * plane;
+    const int y = r / Wp - 1, xx = r - (y + 1) * Wp - 1;
+    img[i] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[((size_t)(b * C + c) * H + y) * W + xx] : 0.f;
+  }
+  __syncthreads();
+  const int QN = cp >> 2, PPI = 256 / QN;              // channel quads per pixel, pixels per sweep of the workgroup
+  const int q = tid % QN, pl = tid / QN;
+  if (pl >= PPI) return;
+  f32x4 w[9 * C];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = (int)q * 4 + e;
-      const int c = k / 9, tap = k - 9 * c;
-      const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
-      v[e] = (k < 9 * C && sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[(c * H + sy) * W + sx] : 0.f;
+  for (int k = 0; k < 9 * C; ++k) w[k] = *reinterpret_cast<const f32x4 *>(wf + (size_t)k * cp + q * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + q * 4), sh = *reinterpret_cast<const f32x4 *>(shift + q * 4);
+  const int per = (HW + parts - 1) / parts;
+  const int hi = (part + 1) * per < HW ? (part + 1) * per : HW;
+  for (int pix = part * per + pl; pix < hi; pix += PPI) {
+    const int y = pix / W, xx = pix - y * W;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float v = img[c * plane + (y + t / 3) * Wp + xx + t % 3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, w[c * 9 + t][e], acc[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e] * sc[e] + sh[e], 0.f);
+    for (int pass = 0; pass < n_pass; ++pass) {
+      const int bt = pass * B + b;
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(tb + (size_t)(bt / tb_div) * tb_stride + q * 4);
+      *reinterpret_cast<f32x4 *>(out + ((size_t)bt * HW + pix) * cp + q * 4) = acc + t;
     }
-    reinterpret_cast<float4 *>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
-int launch_im2col3(const float *x, float *out, int B, int n_pass, int C, int H, int W, int kp, hipStream_t s) {
-  const size_t total = (size_t)n_pass * B * H * W * (kp / 4);
-  if (kp % 4 || total >= (1ull << 32)) return DT_E_SHAPE;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  ProfileScope prof(KC_IM2COL, 0.0, 4.0 * B * H * W * (C + (double)n_pass * kp), s);
-  im2col3_kernel<<<blocks, 256, 0, s>>>(x, out, B, n_pass, C, H, W, kp);
+int launch_first_conv(const float *x, const float *wf, const float *scale, const float *shift, const float *tb, int tb_stride,
+                      int tb_div, float *out, int B, int n_pass, int C, int H, int W, int cout, int cout_p, hipStream_t s) {
+  if (C < 1 || C > 3 || cout_p % 4 || cout_p > 1024) return DT_E_SHAPE;
+  const size_t lds = (size_t)C * (H + 2) * (W + 2) * sizeof(float);
+  if (lds > 64 * 1024) return DT_E_SHAPE;
+  const int parts = B >= 1024 ? 1 : (B >= 256 ? 4 : 8);            // enough workgroups to cover the chip at small batches
+  ProfileScope prof(KC_FIRST_CONV, 2.0 * n_pass * B * H * W * (double)cout * 9 * C, 4.0 * B * H * W * (C + (double)n_pass * cout_p), s);
+  if (C == 1) first_conv_kernel<1><<<B * parts, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
+  else if (C == 2) first_conv_kernel<2><<<B * parts, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
+  else first_conv_kernel<3><<<B * parts, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// conv1.weight OIHW [cout][C][3][3] -> wf[k = c*9 + tap][cout_p] (zero on padding channels)
+__global__ void pack_first_conv_kernel(const float *__restrict__ w, float *__restrict__ wf, int cout, int C, int cp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * C * cp) return;
+  const int k = i / cp, n = i - k * cp;
+  wf[i] = n < cout ? w[(size_t)n * 9 * C + k] : 0.f;
+}
+
+int launch_pack_first_conv(const float *w_oihw, float *wf, int cout, int C, int cout_p, hipStream_t s) {
+  pack_first_conv_kernel<<<(9 * C * cout_p + 255) / 256, 256, 0, s>>>(w_oihw, wf, cout, C, cout_p);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

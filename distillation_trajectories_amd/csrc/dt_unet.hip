@@ -2,7 +2,7 @@
 // device-resident reverse-diffusion loop and the extern "C" surface declared in include/dt_hip.h.
 //
 // Plan of one forward (reference models.py:159-224), NHWC activations with channels padded to 16:
-//   x(NCHW) -> a0[Bt,H,W,16]
+//   x(NCHW) -> enc1.conv1 (direct fp32 conv, shared by the passes)
 //   enc1 @H      -> pool -> enc2 @H/2 -> pool -> enc3 @H/4 -> pool -> enc4 @H/8 -> pool -> bottleneck @H/16
 //   up+cat(enc4) -> dec3 @H/8 -> up+cat(enc3) -> dec2 @H/4 -> up+cat(enc2) -> dec1 @H/2 -> up + 1x1 head @H
 // Each residual block is up to three implicit-GEMM launches (1x1 skip, conv1, conv2) whose epilogues
@@ -55,7 +55,7 @@ const char *kClassName[KC_COUNT] = {
     "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
     "conv_gemm_bf16x6_kernel<64,64>",
     "conv_strip_bf16x6_kernel<128,128>", "conv_strip_bf16x6_kernel<128,64>", "conv_strip_bf16x6_kernel<64,128>",
-    "conv_strip_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "im2col3_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "conv_strip_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "first_conv_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
@@ -120,7 +120,6 @@ struct dt_unet {
   dt_unet_desc desc;
   BlockW blk[kBlocks];
   int cp[4];              // padded dims
-  int kp0;                // padded K of the first-layer im2col (9*C rounded up to 16)
   int tb_stride;
   float *slab;            // one device allocation holding everything below
   size_t slab_floats;
@@ -137,7 +136,6 @@ struct Bump {
 
 // activation buffers of one forward, as float offsets into the workspace
 struct Plan {
-  size_t a0;                                   // first-layer patches [Bt*H*W][kp0]
   size_t h[kBlocks], r[kBlocks], o[kBlocks];   // conv1 out, skip out, block out
   size_t pool[4], cat[3];
   size_t slab, lowres;                         // split-K partial sums; low-resolution head output
@@ -151,7 +149,6 @@ const int kDiv[kBlocks] = {1, 2, 4, 8, 16, 8, 4, 2};
 Plan make_plan(const dt_unet *u, int Bt, int H, int W) {
   Plan p{};
   Bump b;
-  p.a0 = b.take((size_t)Bt * H * W * u->kp0);
   size_t slab = 0;
   for (int j = 0; j < kBlocks; ++j) {
     const int h = H / kDiv[j], w = W / kDiv[j];
@@ -188,7 +185,7 @@ const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W) {
 // Parameters of conv slot `slot` (0 = 1x1 skip, 1 = conv1, 2 = conv2) of block j; returns false when the
 // block has no such launch (identity skips, and enc1 whose skip is recomputed in conv2's epilogue).
 bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, const Plan &pl, int Bt, const float *tb,
-               int tb_div, const ConvChoice *choice, ConvParams &p) {
+               int tb_div, const ConvChoice *choice, ConvParams &p, int x_imgs = 1) {
   const BlockW &k = u->blk[j];
   const int h = pl.H[j], w = pl.W[j];
   const bool dot = h == 1 && w == 1;   // a 1x1 image only ever sees the centre tap of a padded 3x3 kernel
@@ -207,8 +204,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   } else if (slot == 1) {
     p.w = k.w1; p.scale = k.s1; p.shift = k.h1; p.tb = tb + k.tb_off; p.out = ws + pl.h[j]; p.relu = 1;
     if (j == 0) {
-      // enc1: `in` holds the im2col patches, conv1 is a 1x1 GEMM over K = kp0
-      p.ksize = 1; p.tap_lo = 0; p.tap_hi = 1;
+      return false;   // enc1.conv1 is the direct first-layer kernel (launch_first_conv), not an implicit GEMM
     } else {
       p.ksize = 3; p.tap_lo = dot ? 4 : 0; p.tap_hi = dot ? 5 : 9;
       taps = dot ? 1 : 9;
@@ -220,7 +216,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     taps = dot ? 1 : 9;
     if (j == 0) {
       // the C-channel skip of enc1 is recomputed in the epilogue from the patches' centre taps (k = 9c+4)
-      p.x3 = in + 4; p.w3 = k.w3; p.x3_stride = u->kp0; p.x3_step = 9; p.x3_c = u->desc.channels;
+      p.x3 = in; p.w3 = k.w3; p.x3_hw = h * w; p.x3_imgs = x_imgs; p.x3_c = u->desc.channels;   // `in` is the NCHW image
       taps = 1;   // keeps the fused (non-split) epilogue
     } else {
       p.add = k.has_res ? ws + pl.r[j] : in;   // identity skip: cin_p == cout_p
@@ -267,7 +263,7 @@ bool concat_in_place(const dt_unet *u, int j, float *ws, const Plan &pl, int Bt,
 }
 
 int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
-              const TunedShape *tuned, hipStream_t s) {
+              const TunedShape *tuned, hipStream_t s, int x_imgs) {
   ConvParams p;
   bool fused_skip = false;
   if (u->blk[j].has_res && j > 0) {   // is conv2 going to fold the skip in?
@@ -276,9 +272,15 @@ int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &p
     fused_skip = c2.in2 != nullptr;
   }
   const bool in_place = concat_in_place(u, j, ws, pl, Bt, tb, tb_div, tuned);
+  if (j == 0) {
+    const BlockW &k = u->blk[0];
+    const int st = launch_first_conv(in, k.w1, k.s1, k.h1, tb + k.tb_off, u->tb_stride, tb_div, ws + pl.h[0], x_imgs, Bt / x_imgs,
+                                     u->desc.channels, pl.H[0], pl.W[0], k.cout, k.cout_p, s);
+    if (st) return st;
+  }
   for (int slot = 0; slot < 3; ++slot) {
     if (slot == 0 && fused_skip) continue;
-    if (!conv_slot(u, j, slot, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][slot] : nullptr, p)) continue;
+    if (!conv_slot(u, j, slot, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][slot] : nullptr, p, x_imgs)) continue;
     if (in_place) {
       const int skip = 8 - j;            // dec3<-enc4(3), dec2<-enc3(2), dec1<-enc2(1)
       p.cc_a = u->blk[j].split_cp >> 4;
@@ -300,9 +302,8 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
   const Plan pl = make_plan(u, Bt, H, W);
   if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
   const TunedShape *tuned = find_tuned(u, Bt, H, W);
-  int st = launch_im2col3(x, ws + pl.a0, B, n_pass, u->desc.channels, H, W, u->kp0, s);
-  if (st) return st;
-  const float *cur = ws + pl.a0;
+  int st = DT_OK;
+  const float *cur = x;                     // enc1 reads the NCHW image itself (first-layer kernel, skip in conv2's epilogue)
   for (int j = 0; j < kBlocks; ++j) {
     if (j >= 1 && j <= 4) {        // encoder: pool the previous block's output (unless its conv2 already did)
       ConvParams prev;
@@ -320,7 +321,7 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
       if (st) return st;
       cur = ws + pl.cat[j - 5];
     }
-    st = run_block(u, j, cur, ws, pl, Bt, tb, tb_div, tuned, s);
+    st = run_block(u, j, cur, ws, pl, Bt, tb, tb_div, tuned, s, B);
     if (st) return st;
   }
   return launch_head(ws + pl.o[7], u->final_w, u->final_b, ws + pl.lowres, eps, Bt, pl.H[7], pl.W[7], u->blk[7].cout_p,
@@ -360,7 +361,6 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   const int C = desc->channels, D = desc->temb_dim;
   const int *d = desc->dims;
   for (int i = 0; i < 4; ++i) u->cp[i] = round_up(d[i], kChanPad);
-  u->kp0 = round_up(9 * C, kChanPad);
   // (cin, cout) and the concat split of the eight blocks -- models.py:138-154
   const int cin[kBlocks] = {C, d[0], d[1], d[2], d[3], d[3] + d[3], d[2] + d[2], d[1] + d[1]};
   const int cout[kBlocks] = {d[0], d[1], d[2], d[3], d[3], d[2], d[1], d[0]};
@@ -378,7 +378,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
       k.split_c = up_c[j]; k.split_cp = round_up(up_c[j], kChanPad);
       k.cin_p = k.split_cp + round_up(cin[j] - up_c[j], kChanPad);
     } else {
-      k.cin_p = j == 0 ? u->kp0 : round_up(cin[j], kChanPad);   // enc1.conv1 consumes im2col patches
+      k.cin_p = round_up(cin[j], kChanPad);                    // (enc1.conv1 is the direct first-layer kernel)
       k.split_c = cin[j]; k.split_cp = k.cin_p;
     }
     k.has_res = cin[j] != cout[j];
@@ -386,11 +386,11 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
       const bool optional = t == DT_BT_RES_W || t == DT_BT_RES_B;
       if (!bt[j * DT_BT_COUNT + t] && (!optional || k.has_res)) { delete u; return DT_E_NULL; }
     }
-    o_w1[j] = bump.take((size_t)(j == 0 ? 1 : 9) * k.cin_p * k.n_p);
+    o_w1[j] = bump.take(j == 0 ? (size_t)9 * C * k.cout_p : (size_t)9 * k.cin_p * k.n_p);   // enc1: wf[9C][cout_p]
     o_w2[j] = bump.take((size_t)9 * k.cout_p * k.n_p);
     o_wr[j] = k.has_res ? bump.take(j == 0 ? (size_t)4 * k.n_p : (size_t)k.cin_p * k.n_p) : 0;
     o_ss[j] = bump.take((size_t)6 * k.n_p);
-    o_w1b[j] = bump.take((size_t)(j == 0 ? 1 : 9) * k.cin_p * k.n_p * 3 / 2);
+    o_w1b[j] = j == 0 ? 0 : bump.take((size_t)9 * k.cin_p * k.n_p * 3 / 2);
     o_w2b[j] = bump.take((size_t)9 * k.cout_p * k.n_p * 3 / 2);
     o_wrb[j] = (k.has_res && j > 0) ? bump.take((size_t)k.cin_p * k.n_p * 3 / 2) : 0;
     k.tb_off = tb;
@@ -422,15 +422,14 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
     k.w1b = S + o_w1b[j]; k.w2b = S + o_w2b[j]; k.wrb = (k.has_res && j > 0) ? S + o_wrb[j] : nullptr;
     float *ss = S + o_ss[j];
     k.s1 = ss; k.h1 = ss + k.n_p; k.s2 = ss + 2 * k.n_p; k.h2 = ss + 3 * k.n_p; k.sr = ss + 4 * k.n_p; k.hr = ss + 5 * k.n_p;
-    if (j == 0)   // OIHW [cout][C][3][3] read as a [cout][9C] matrix: a 1x1 conv over the im2col patches
-      st = launch_pack_conv(t[DT_BT_CONV1_W], k.w1, k.cout, 9 * C, 1, k.cin_p, k.n_p, 9 * C, k.cin_p, s);
+    if (j == 0)
+      st = launch_pack_first_conv(t[DT_BT_CONV1_W], k.w1, k.cout, C, k.cout_p, s);
     else
       st = launch_pack_conv(t[DT_BT_CONV1_W], k.w1, k.cout, k.cin, 3, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
     if (!st) st = launch_pack_conv(t[DT_BT_CONV2_W], k.w2, k.cout, k.cout, 3, k.cout_p, k.n_p, k.cout, k.cout_p, s);
     if (!st && k.has_res && j > 0)
       st = launch_pack_conv(t[DT_BT_RES_W], k.wr, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
-    if (!st) st = j == 0 ? launch_pack_conv_bf16x3(t[DT_BT_CONV1_W], k.w1b, k.cout, 9 * C, 1, k.cin_p, k.n_p, 9 * C, k.cin_p, s)
-                         : launch_pack_conv_bf16x3(t[DT_BT_CONV1_W], k.w1b, k.cout, k.cin, 3, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
+    if (!st && j > 0) st = launch_pack_conv_bf16x3(t[DT_BT_CONV1_W], k.w1b, k.cout, k.cin, 3, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
     if (!st) st = launch_pack_conv_bf16x3(t[DT_BT_CONV2_W], k.w2b, k.cout, k.cout, 3, k.cout_p, k.n_p, k.cout, k.cout_p, s);
     if (!st && k.has_res && j > 0)
       st = launch_pack_conv_bf16x3(t[DT_BT_RES_W], k.wrb, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
@@ -509,7 +508,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
     if (hipStreamSynchronize(s) != hipSuccess) st = (int)hipGetLastError();
   }
   for (int j = 0; j < kBlocks && st == DT_OK; ++j) {
-    const float *in = j == 0 ? ws + pl.a0 : (j <= 4 ? ws + pl.pool[j - 1] : ws + pl.cat[j - 5]);
+    const float *in = j == 0 ? ws + pl.h[0] : (j <= 4 ? ws + pl.pool[j - 1] : ws + pl.cat[j - 5]);   // (enc1: stands in for the image)
     float skip_ms = 0.f;
     for (int slot = 0; slot < 3 && st == DT_OK; ++slot) {
       ConvParams p;
@@ -631,7 +630,7 @@ int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block
   const Plan pl = make_plan(h, batch_total, H, W);
   if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
   float *ws = (float *)workspace;
-  const float *in = block == 0 ? ws + pl.a0 : (block <= 4 ? ws + pl.pool[block - 1] : ws + pl.cat[block - 5]);
+  const float *in = block == 0 ? ws + pl.h[0] : (block <= 4 ? ws + pl.pool[block - 1] : ws + pl.cat[block - 5]);
   const ConvChoice c{bm, bn, splits, prec, fuse};
   ConvParams p;
   if (!conv_slot(h, block, slot, in, ws, pl, batch_total, h->slab, batch_total, &c, p)) { *ms = 0.f; *flops = 0.0; return DT_OK; }
