@@ -39,6 +39,7 @@ SIGNATURES = {
                                     POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "dt_unet_set_conv_choice": (c_int, [c_void_p] + [c_int] * 10),
     "dt_unet_set_precision": (c_int, [c_void_p, c_int]),
+    "dt_unet_set_head_fusion": (c_int, [c_void_p, c_int]),
     "dt_unet_time_conv": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, c_size_t, c_void_p, POINTER(c_float), POINTER(c_double)]),
     "dt_unet_debug_activation": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_int),

@@ -198,63 +198,92 @@ ConvChoice heuristic_choice(int M, int n_p, int taps) {
 
 // sum of the split-K slabs in z order + the layer epilogue, float4 over channels.  S = compile-time slab count
 // (all S loads of an element are issued before the first add); S = 0 walks p.splits at run time.
+// POOL: a thread owns a 2x2 window of one picture (four rows of the output) and also writes their maximum to
+// p.pool_out (the encoder's max pool, folded in so that split layers do not need a separate pooling launch).
 template <int S>
+__device__ inline float4 splitk_finish(const ConvParams &p, unsigned m, int n, size_t slab_stride) {
+  const size_t o = (size_t)m * p.cout_p + n;
+  float4 a;
+  if (S > 0) {
+    float4 part[S > 0 ? S : 1];
+#pragma unroll
+    for (int z = 0; z < S; ++z) part[z] = *reinterpret_cast<const float4 *>(p.slab + z * slab_stride + o);
+    a = part[0];
+#pragma unroll
+    for (int z = 1; z < S; ++z) { a.x += part[z].x; a.y += part[z].y; a.z += part[z].z; a.w += part[z].w; }
+  } else {
+    a = *reinterpret_cast<const float4 *>(p.slab + o);
+    for (int z = 1; z < p.splits; ++z) {
+      const float4 b = *reinterpret_cast<const float4 *>(p.slab + z * slab_stride + o);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+  }
+  const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n), sh = *reinterpret_cast<const float4 *>(p.shift + n);
+  float4 v = make_float4(a.x * sc.x + sh.x, a.y * sc.y + sh.y, a.z * sc.z + sh.z, a.w * sc.w + sh.w);
+  if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (p.tb) {
+    const float4 t = *reinterpret_cast<const float4 *>(p.tb + (size_t)(m / (unsigned)p.m_per_tb) * p.tb_stride + n);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  if (p.add) {
+    const float4 t = *reinterpret_cast<const float4 *>(p.add + o);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  *reinterpret_cast<float4 *>(p.out + o) = v;
+  return v;
+}
+
+template <int S, bool POOL>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvParams p) {
-  // 32-bit index math (launch_conv guarantees M * cout_p < 2^31); the row is only divided when cout_p / 4 is not a
-  // power of two, and the time-bias row by a 32-bit division per float4 instead of a 64-bit one
+  // 32-bit index math (launch_conv guarantees M * cout_p < 2^31)
   const unsigned c4 = (unsigned)p.cout_p >> 2;
-  const unsigned total = (unsigned)p.M * c4;
   const size_t slab_stride = (size_t)p.M * p.cout_p;
-  const bool pow2 = (c4 & (c4 - 1)) == 0;
-  const int sh4 = 31 - __builtin_clz(c4);
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const unsigned m = pow2 ? i >> sh4 : i / c4;
-    const int n = (int)(i - m * c4) * 4;
-    const size_t o = (size_t)m * p.cout_p + n;
-    float4 a;
-    if (S > 0) {
-      float4 part[S > 0 ? S : 1];
-#pragma unroll
-      for (int z = 0; z < S; ++z) part[z] = *reinterpret_cast<const float4 *>(p.slab + z * slab_stride + o);
-      a = part[0];
-#pragma unroll
-      for (int z = 1; z < S; ++z) { a.x += part[z].x; a.y += part[z].y; a.z += part[z].z; a.w += part[z].w; }
-    } else {
-      a = *reinterpret_cast<const float4 *>(p.slab + o);
-      for (int z = 1; z < p.splits; ++z) {
-        const float4 b = *reinterpret_cast<const float4 *>(p.slab + z * slab_stride + o);
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-      }
+  if (!POOL) {
+    const unsigned total = (unsigned)p.M * c4;
+    const bool pow2 = (c4 & (c4 - 1)) == 0;
+    const int sh4 = 31 - __builtin_clz(c4);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+      const unsigned m = pow2 ? i >> sh4 : i / c4;
+      splitk_finish<S>(p, m, (int)(i - m * c4) * 4, slab_stride);
     }
-    const float4 sc = *reinterpret_cast<const float4 *>(p.scale + n), sh = *reinterpret_cast<const float4 *>(p.shift + n);
-    float4 v = make_float4(a.x * sc.x + sh.x, a.y * sc.y + sh.y, a.z * sc.z + sh.z, a.w * sc.w + sh.w);
-    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (p.tb) {
-      const float4 t = *reinterpret_cast<const float4 *>(p.tb + (size_t)(m / (unsigned)p.m_per_tb) * p.tb_stride + n);
-      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  } else {
+    const unsigned Wo = (unsigned)p.W >> 1, Ho = (unsigned)p.H >> 1, HW = (unsigned)(p.H * p.W);
+    const unsigned total = ((unsigned)p.M >> 2) * c4;                    // one thread per (2x2 window, channel quad)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+      const unsigned wq = i / c4;
+      const int n = (int)(i - wq * c4) * 4;
+      const unsigned xo = wq % Wo, r = wq / Wo;
+      const unsigned yo = r % Ho, b = r / Ho;
+      const unsigned m00 = b * HW + 2 * yo * (unsigned)p.W + 2 * xo;
+      const float4 a = splitk_finish<S>(p, m00, n, slab_stride), bq = splitk_finish<S>(p, m00 + 1, n, slab_stride);
+      const float4 c = splitk_finish<S>(p, m00 + p.W, n, slab_stride), d = splitk_finish<S>(p, m00 + p.W + 1, n, slab_stride);
+      float4 mx;
+      mx.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(c.x, d.x)); mx.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(c.y, d.y));
+      mx.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(c.z, d.z)); mx.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(c.w, d.w));
+      *reinterpret_cast<float4 *>(p.pool_out + (size_t)wq * p.cout_p + n) = mx;
     }
-    if (p.add) {
-      const float4 t = *reinterpret_cast<const float4 *>(p.add + o);
-      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-    }
-    *reinterpret_cast<float4 *>(p.out + o) = v;
   }
 }
 
-int launch_splitk_epilogue(const ConvParams &p, hipStream_t s) {
-  const size_t total = (size_t)p.M * (p.cout_p / 4);
+template <bool POOL>
+static int launch_splitk_epilogue_t(const ConvParams &p, hipStream_t s) {
+  const size_t total = (size_t)(POOL ? p.M / 4 : p.M) * (p.cout_p / 4);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  ProfileScope prof(KC_SPLITK_EPILOGUE, 0.0, 4.0 * p.M * p.cout_p * (p.splits + 1.0), s);
+  ProfileScope prof(KC_SPLITK_EPILOGUE, 0.0, 4.0 * p.M * p.cout_p * (p.splits + 1.0 + (POOL ? 0.25 : 0.0)), s);
   switch (p.splits) {
-    case 2: splitk_epilogue_kernel<2><<<blocks, 256, 0, s>>>(p); break;
-    case 3: splitk_epilogue_kernel<3><<<blocks, 256, 0, s>>>(p); break;
-    case 4: splitk_epilogue_kernel<4><<<blocks, 256, 0, s>>>(p); break;
-    case 8: splitk_epilogue_kernel<8><<<blocks, 256, 0, s>>>(p); break;
-    case 9: splitk_epilogue_kernel<9><<<blocks, 256, 0, s>>>(p); break;
-    default: splitk_epilogue_kernel<0><<<blocks, 256, 0, s>>>(p); break;
+    case 2: splitk_epilogue_kernel<2, POOL><<<blocks, 256, 0, s>>>(p); break;
+    case 3: splitk_epilogue_kernel<3, POOL><<<blocks, 256, 0, s>>>(p); break;
+    case 4: splitk_epilogue_kernel<4, POOL><<<blocks, 256, 0, s>>>(p); break;
+    case 8: splitk_epilogue_kernel<8, POOL><<<blocks, 256, 0, s>>>(p); break;
+    case 9: splitk_epilogue_kernel<9, POOL><<<blocks, 256, 0, s>>>(p); break;
+    default: splitk_epilogue_kernel<0, POOL><<<blocks, 256, 0, s>>>(p); break;
   }
   DT_LAUNCH_CHECK();
   return DT_OK;
+}
+
+int launch_splitk_epilogue(const ConvParams &p, hipStream_t s) {
+  return p.pool_out ? launch_splitk_epilogue_t<true>(p, s) : launch_splitk_epilogue_t<false>(p, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -144,6 +144,38 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
         }
       }
     }
+    if (p.head_out) {
+      // final 1x1 head on the rows this workgroup holds completely: C4 consecutive lanes own one row
+      f32x4 hw[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        hw[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < p.head_c && n_ok) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.head_cin) hw[c][e] = p.head_w[c * p.head_cin + n + e];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        float part[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          part[c] = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part[c] = fmaf(hw[c][e], v[k][e], part[c]);
+#pragma unroll
+          for (int off = C4 / 2; off > 0; off >>= 1) part[c] += __shfl_xor(part[c], off, 64);
+        }
+        if (c4 == 0 && mrow[k] < p.M) {
+          f32x4 o = {part[0] + p.head_b[0], 0.f, 0.f, 0.f};
+          if (p.head_c > 1) o[1] = part[1] + p.head_b[1];
+          if (p.head_c > 2) o[2] = part[2] + p.head_b[2];
+          *reinterpret_cast<f32x4 *>(p.head_out + (size_t)mrow[k] * 4) = o;
+        }
+      }
+      continue;                                        // dec1's output itself has no other consumer
+    }
 #pragma unroll
     for (int k = 0; k < U; ++k)
       if (ok[k]) *reinterpret_cast<f32x4 *>(p.out + (size_t)mrow[k] * p.cout_p + n) = v[k];

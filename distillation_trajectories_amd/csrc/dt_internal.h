@@ -36,6 +36,22 @@ struct ProfileScope {
   hipStream_t stream;
 };
 
+// bilinear source coordinates for scale factor 2 with align_corners=True (ATen area_pixel_compute_scale:
+// scale = (in-1)/(out-1), 0 when out == 1; src = scale*dst), and the four-tap blend with its operation order fixed by
+// explicit fmaf so that every translation unit (whatever its fp-contract setting) produces the same bits
+__device__ inline void bilinear_src(int dst, int in, int out, int &i0, int &i1, float &l0, float &l1) {
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)dst;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+__device__ inline float bilinear_blend(float v00, float v01, float v10, float v11, float wy0, float wy1, float wx0, float wx1) {
+  const float top = fmaf(wx1, v01, wx0 * v00), bot = fmaf(wx1, v11, wx0 * v10);
+  return fmaf(wy1, bot, wy0 * top);
+}
+
 constexpr int kChanPad = 16;   // activation channel granularity (= BK of the conv GEMM)
 constexpr int kNPad = 64;      // packed-weight N granularity (smallest BN tile)
 constexpr int kBlocks = 8;
@@ -90,6 +106,12 @@ struct ConvParams {
   // so the concat buffer's skip half is never written
   const float *in_b, *in2_b;
   int cc_a, b_stride;
+  // final 1x1 head (models.py:221-224) folded into dec1.conv2's epilogue when one workgroup holds every output channel
+  // of its rows (n_p == BN): lowres[m][c] = sum_n v[m][n] * head_w[c * head_cin + n] + head_b[c], c < head_c <= 3, stored
+  // as float4 per pixel; `out` is then not written at all (the head is dec1's only consumer)
+  const float *head_w, *head_b;
+  float *head_out;
+  int head_c, head_cin;
   int ablate;          // timing experiments only (wrong results): 1 no barrier, 2 no LDS reads, 3 no MFMA, 4 no staging
 };
 
@@ -119,8 +141,9 @@ int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hi
 // skip == nullptr: only the upsampled channels are written (the consumers read the skip half in place)
 int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p,
                  hipStream_t s);
-int launch_head(const float *lo, const float *w, const float *bias, float *lowres, float *eps, int Bt, int h, int w_,
-                int cp, int C, int c_real, hipStream_t s);
+int launch_head(const float *lo, const float *w, const float *bias, float *lowres, int Bt, int h, int w_, int cp, int C, int c_real,
+                hipStream_t s);
+int launch_head_upsample(const float *lowres, float *eps, int Bt, int h, int w_, int C, hipStream_t s);
 int launch_pack_res3(const float *w, const float *b, float *w3, int cout, int C, int n_p, hipStream_t s);
 
 struct TembWeights {

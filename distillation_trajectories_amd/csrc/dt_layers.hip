@@ -116,17 +116,6 @@ int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hi
   return DT_OK;
 }
 
-// bilinear source coordinates for scale factor 2 with align_corners=True (ATen
-// area_pixel_compute_scale: scale = (in-1)/(out-1), 0 when out == 1; src = scale*dst)
-__device__ inline void bilinear_src(int dst, int in, int out, int &i0, int &i1, float &l0, float &l1) {
-  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-  const float src = scale * (float)dst;
-  i0 = (int)src;
-  i1 = i0 + (i0 < in - 1 ? 1 : 0);
-  l1 = src - (float)i0;
-  l0 = 1.f - l1;
-}
-
 // out[b][y][x][0:c1p] = bilinear_x2(lo[b]), out[...][c1p:c1p+c2p] = skip[b][y][x]  (torch.cat dim=1)
 __global__ void upcat_kernel(const float4 *__restrict__ lo, const float4 *__restrict__ skip, float4 *__restrict__ out,
                              int Bt, int h, int w, int c1q, int c2q) {
@@ -234,20 +223,23 @@ __global__ void head_upsample_kernel(const float *__restrict__ lowres, float *__
     const float *base = lowres + b * h * w * 4 + c;
     const float v00 = base[((size_t)y0 * w + x0) * 4], v01 = base[((size_t)y0 * w + x1) * 4];
     const float v10 = base[((size_t)y1 * w + x0) * 4], v11 = base[((size_t)y1 * w + x1) * 4];
-    eps[i] = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+    eps[i] = bilinear_blend(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
   }
 }
 
-int launch_head(const float *lo, const float *wf, const float *bias, float *lowres, float *eps, int Bt, int h, int w,
-                int cp, int C, int c_real, hipStream_t s) {
+int launch_head(const float *lo, const float *wf, const float *bias, float *lowres, int Bt, int h, int w, int cp, int C, int c_real,
+                hipStream_t s) {
   if (C > 3) return DT_E_SHAPE;
   const size_t n_pix = (size_t)Bt * h * w;
-  {
-    const size_t blocks = (n_pix + 31) / 32;             // 8 lanes per pixel
-    ProfileScope prof(KC_HEAD, 2.0 * n_pix * C * c_real, 4.0 * n_pix * (c_real + 4.0), s);
-    head_kernel<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, s>>>(lo, wf, bias, lowres, n_pix, cp, C, c_real);
-    DT_LAUNCH_CHECK();
-  }
+  const size_t blocks = (n_pix + 31) / 32;             // 8 lanes per pixel
+  ProfileScope prof(KC_HEAD, 2.0 * n_pix * C * c_real, 4.0 * n_pix * (c_real + 4.0), s);
+  head_kernel<<<(int)(blocks < 8192 ? blocks : 8192), 256, 0, s>>>(lo, wf, bias, lowres, n_pix, cp, C, c_real);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+int launch_head_upsample(const float *lowres, float *eps, int Bt, int h, int w, int C, hipStream_t s) {
+  const size_t n_pix = (size_t)Bt * h * w;
   const size_t total = n_pix * 4 * C;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   ProfileScope prof(KC_HEAD_UP, 0.0, 4.0 * n_pix * (4.0 + 4.0 * C), s);

@@ -21,6 +21,9 @@ namespace dt {
 int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec, const float *z,
                       const int32_t *z_row, long long z_shift, const float coef[4], int has_noise, const float *w,
                       float w_scalar, float *out, int B, int E, hipStream_t s);
+int launch_cfg_update_lowres(int rule, const float *x, const float *lowres_u, const float *lowres_c, const float *z,
+                             const int32_t *z_row, long long z_shift, const float coef[4], int has_noise, const float *w,
+                             float w_scalar, float *out, int B, int C, int H, int W, hipStream_t s);
 int launch_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, int E, double *out, hipStream_t s);
 int launch_wasserstein(const float *X, const float *Y, int n, int B, int E, const int32_t *index,
                        const int32_t *index_row, int n_idx, double *out, hipStream_t s);
@@ -117,6 +120,7 @@ struct dt_unet {
   mutable std::vector<LoopGraph> graphs;
   mutable std::mutex graph_mu;
   int precision;          // DT_PREC_*: which convolution arithmetic the heuristic / autotuner may use
+  bool head_fusion = true;   // dec1.conv2's epilogue evaluates the final 1x1 head (dt_unet_set_head_fusion)
   dt_unet_desc desc;
   BlockW blk[kBlocks];
   int cp[4];              // padded dims
@@ -239,9 +243,15 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
                   : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
   // encoder blocks enc1..enc4 feed a 2x2 max pool: folded into this launch's staged epilogue where a 32-row tile holds
-  // whole row pairs (W a power of two <= 16)
-  if (slot == 2 && j <= 3 && c.splits == 1 && w >= 2 && w <= 16 && (w & (w - 1)) == 0 && h % 2 == 0) p.pool_out = ws + pl.pool[j];
+  // whole row pairs (W a power of two <= 16); split launches pool in their slab-summing epilogue kernel instead
+  if (slot == 2 && j <= 3 && h % 2 == 0 && w % 2 == 0 && (c.splits > 1 || (w <= 16 && (w & (w - 1)) == 0))) p.pool_out = ws + pl.pool[j];
   if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
+  // dec1.conv2 also evaluates the final 1x1 head when its workgroups hold whole rows (one N tile, no split): the head
+  // is dec1's only consumer, so dec1's own output is then never written
+  if (slot == 2 && j == kBlocks - 1 && u->head_fusion && c.splits == 1 && p.n_p == c.bn && u->desc.channels <= 3) {
+    p.head_w = u->final_w; p.head_b = u->final_b; p.head_out = ws + pl.lowres;
+    p.head_c = u->desc.channels; p.head_cin = u->desc.dims[0];
+  }
   if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0 && !(c.prec == 4 && (k.cin_p >> 4) % 2)) {
     // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
     p.add = nullptr;
@@ -296,7 +306,7 @@ int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &p
 
 int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int W, const float *tb, int tb_div,
                  float *eps, float *ws, size_t ws_bytes, hipStream_t s) {
-  if (!u || !x || !tb || !eps || !ws) return DT_E_NULL;
+  if (!u || !x || !tb || !ws) return DT_E_NULL;
   if (B < 1 || n_pass < 1 || tb_div < 1 || H < 16 || W < 16 || H % 16 || W % 16) return DT_E_SHAPE;
   const int Bt = B * n_pass;
   const Plan pl = make_plan(u, Bt, H, W);
@@ -324,9 +334,20 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
     st = run_block(u, j, cur, ws, pl, Bt, tb, tb_div, tuned, s, B);
     if (st) return st;
   }
-  return launch_head(ws + pl.o[7], u->final_w, u->final_b, ws + pl.lowres, eps, Bt, pl.H[7], pl.W[7], u->blk[7].cout_p,
-                     u->desc.channels, u->desc.dims[0], s);
+  {   // head at the low resolution (unless dec1.conv2's epilogue already produced it), then the 3-channel upsample
+    ConvParams last;
+    conv_slot(u, kBlocks - 1, 2, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[kBlocks - 1][2] : nullptr, last);
+    if (!last.head_out)
+      st = launch_head(ws + pl.o[7], u->final_w, u->final_b, ws + pl.lowres, Bt, pl.H[7], pl.W[7], u->blk[7].cout_p,
+                       u->desc.channels, u->desc.dims[0], s);
+    if (st) return st;
+  }
+  if (!eps) return DT_OK;                  // the sampler's fused update interpolates the low-resolution output itself
+  return launch_head_upsample(ws + pl.lowres, eps, Bt, pl.H[7], pl.W[7], u->desc.channels, s);
 }
+
+// float offset of the low-resolution head output [Bt][H/2][W/2][4] inside the workspace
+size_t lowres_offset(const dt_unet *u, int Bt, int H, int W) { return make_plan(u, Bt, H, W).lowres; }
 
 }  // namespace
 
@@ -479,6 +500,7 @@ size_t dt_unet_workspace_bytes(const dt_unet *h, int batch_total, int H, int W) 
 
 int dt_unet_forward(const dt_unet *h, const float *x, int B, int n_pass, int H, int W, const float *tb, int tb_div,
                     float *eps, void *ws, size_t ws_bytes, void *stream) {
+  if (!eps) return DT_E_NULL;
   return forward_impl(h, x, B, n_pass, H, W, tb, tb_div, eps, (float *)ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -564,6 +586,8 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       for (int bm = 64; bm <= 128; bm += 64)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
+          // dec1.conv2 with one N tile also evaluates the head (saves the head launch and dec1's output round trip)
+          if (j == kBlocks - 1 && slot == 2 && h->head_fusion && h->desc.channels <= 3 && p.n_p <= 128 && bn != p.n_p) continue;
           // 3x3 walks split by taps 1/3/9; the strip kernel and single-tap layers by channel chunks 1/2/4/8
           const long long tiles = (long long)((p.M + bm - 1) / bm) * (p.n_p / bn);
           for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= ((prec >= 3 || !walk9) ? 2 : 3))
@@ -661,6 +685,13 @@ int dt_unet_set_precision(dt_unet *h, int precision) {
   return DT_OK;
 }
 
+int dt_unet_set_head_fusion(dt_unet *h, int on) {
+  if (!h) return DT_E_NULL;
+  h->head_fusion = on != 0;
+  drop_graphs(h);
+  return DT_OK;
+}
+
 /* test / report hook: the (bm, bn, splits) in use for block j, slot (0 skip, 1 conv1, 2 conv2) at a shape */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
                         int *splits, int *prec, int *tuned) {
@@ -739,17 +770,20 @@ static int sample_loop(const dt_unet *h, int rule, int B, int n_pass, int H, int
                        void *ws, size_t ws_bytes, hipStream_t s) {
   const int E = h->desc.channels * H * W;
   const size_t slot = (size_t)B * E;
+  if (make_plan(h, B * n_pass, H, W).total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
+  const float *lowres = (const float *)ws + lowres_offset(h, B * n_pass, H, W);
+  (void)eps_scratch;                       // kept in the ABI: callers still hand in the scratch the unfused path used
   for (int i = 0; i < n_steps; ++i) {
     const float *x = traj + (size_t)i * slot;
     float *xn = traj + (size_t)(i + 1) * slot;
     const bool dead = rule == DT_RULE_ENGINE && !has_noise[i];   // t == 0: the prediction is never used
-    if (!dead) {
-      int st = forward_impl(h, x, B, n_pass, H, W, tb + (size_t)i * n_pass * h->tb_stride, B, eps_scratch, (float *)ws,
-                            ws_bytes, s);
+    if (!dead) {      // the forward stops at the low-resolution head output; the update interpolates it (no eps tensor)
+      int st = forward_impl(h, x, B, n_pass, H, W, tb + (size_t)i * n_pass * h->tb_stride, B, nullptr, (float *)ws, ws_bytes, s);
       if (st) return st;
     }
-    int st = launch_cfg_update(rule, x, eps_scratch, n_pass == 2 ? eps_scratch + slot : nullptr, z, z_row,
-                               z_shift ? (long long)z_shift[i] : 0, coef + 4 * i, has_noise[i], w, w_scalar, xn, B, E, s);
+    int st = launch_cfg_update_lowres(rule, x, lowres, n_pass == 2 ? lowres + (size_t)B * (H / 2) * (W / 2) * 4 : nullptr, z, z_row,
+                                      z_shift ? (long long)z_shift[i] : 0, coef + 4 * i, has_noise[i], w, w_scalar, xn, B,
+                                      h->desc.channels, H, W, s);
     if (st) return st;
   }
   return DT_OK;

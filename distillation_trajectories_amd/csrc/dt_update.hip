@@ -16,6 +16,9 @@
 
 namespace dt {
 
+// LOWRES builds: eu / ec are the low-resolution head outputs lowres[b][h][w][4] of the two passes and the prediction
+// is their bilinear x2 upsampling (models.py:221, align_corners=True), evaluated here instead of by a separate
+// head_upsample launch + an eps round trip through HBM; lh, lw = low-resolution size, hw = H*W of the image.
 struct UpdateArgs {
   const float *x, *eu, *ec, *z;
   const int32_t *z_row;
@@ -24,6 +27,7 @@ struct UpdateArgs {
   float c0, c1, c2, w_scalar;
   long long z_shift;   // added to the z row index (rows of E floats)
   int has_noise, B, E4;
+  int lh, lw, hw;
 };
 
 template <int RULE>
@@ -40,7 +44,29 @@ __device__ inline float step1(float x, float eps, float z, const UpdateArgs &a, 
   }
 }
 
-template <int RULE>
+// eps of element (b, c, y, x..x+3) from a low-resolution head output (same arithmetic as head_upsample_kernel)
+__device__ inline float4 eps_from_lowres(const float *lowres, int b, int e, const UpdateArgs &a) {
+  const int W = 2 * a.lw, H = 2 * a.lh;
+  const int idx = e * 4, c = idx / a.hw, pix = idx - c * a.hw;
+  const int y = pix / W, x0 = pix - y * W;
+  int y0, y1;
+  float wy0, wy1;
+  bilinear_src(y, a.lh, H, y0, y1, wy0, wy1);
+  const float *base = lowres + (size_t)b * a.lh * a.lw * 4 + c;
+  float r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int xa, xb;
+    float wx0, wx1;
+    bilinear_src(x0 + j, a.lw, W, xa, xb, wx0, wx1);
+    const float v00 = base[((size_t)y0 * a.lw + xa) * 4], v01 = base[((size_t)y0 * a.lw + xb) * 4];
+    const float v10 = base[((size_t)y1 * a.lw + xa) * 4], v11 = base[((size_t)y1 * a.lw + xb) * 4];
+    r[j] = bilinear_blend(v00, v01, v10, v11, wy0, wy1, wx0, wx1);
+  }
+  return make_float4(r[0], r[1], r[2], r[3]);
+}
+
+template <int RULE, bool LOWRES = false>
 __global__ __launch_bounds__(256) void cfg_update_kernel(const UpdateArgs a) {
   const size_t total = (size_t)a.B * a.E4;
   const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
@@ -52,9 +78,9 @@ __global__ __launch_bounds__(256) void cfg_update_kernel(const UpdateArgs a) {
     const int b = i / a.E4, e = i - (size_t)b * a.E4;
     const float4 xv = x4[i];
     if (RULE == DT_RULE_ENGINE && !a.has_noise) { o4[i] = xv; continue; }   // t == 0: x is recorded unchanged
-    float4 ev = eu4[i];
+    float4 ev = LOWRES ? eps_from_lowres(a.eu, b, e, a) : eu4[i];
     if (a.ec) {
-      const float4 cv = ec4[i];
+      const float4 cv = LOWRES ? eps_from_lowres(a.ec, b, e, a) : ec4[i];
       const float w = a.w ? a.w[b] : a.w_scalar;
       ev.x = ev.x + w * (cv.x - ev.x);
       ev.y = ev.y + w * (cv.y - ev.y);
@@ -86,7 +112,7 @@ int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec
   if (!x || !eu || !out || !coef) return DT_E_NULL;
   if (has_noise && !z) return DT_E_NULL;
   if (B <= 0 || E <= 0 || E % 4) return DT_E_SHAPE;
-  UpdateArgs a{x, eu, ec, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4};
+  UpdateArgs a{x, eu, ec, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4, 0, 0, 0};
   const size_t total = (size_t)B * (E / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   // algorithmic bytes: read x + read z + write x' = 3*E*4 per sample-step (+ eps reads)
@@ -95,6 +121,30 @@ int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec
     case DT_RULE_ENGINE: cfg_update_kernel<DT_RULE_ENGINE><<<blocks, 256, 0, s>>>(a); break;
     case DT_RULE_PSAMPLE: cfg_update_kernel<DT_RULE_PSAMPLE><<<blocks, 256, 0, s>>>(a); break;
     case DT_RULE_MANAGER: cfg_update_kernel<DT_RULE_MANAGER><<<blocks, 256, 0, s>>>(a); break;
+    default: return DT_E_ARG;
+  }
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// the same step with the prediction taken from the low-resolution head outputs of the two passes (lowres_u, lowres_c:
+// [B][H/2][W/2][4]; lowres_c == nullptr: one pass)
+int launch_cfg_update_lowres(int rule, const float *x, const float *lowres_u, const float *lowres_c, const float *z,
+                             const int32_t *z_row, long long z_shift, const float coef[4], int has_noise, const float *w,
+                             float w_scalar, float *out, int B, int C, int H, int W, hipStream_t s) {
+  if (!x || !lowres_u || !out || !coef) return DT_E_NULL;
+  if (has_noise && !z) return DT_E_NULL;
+  const int E = C * H * W;
+  if (B <= 0 || E <= 0 || W % 4 || H % 2 || W % 2) return DT_E_SHAPE;
+  UpdateArgs a{x, lowres_u, lowres_c, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4,
+               H / 2, W / 2, H * W};
+  const size_t total = (size_t)B * (E / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  ProfileScope prof(KC_UPDATE, 0.0, 4.0 * B * E * (2.0 + (has_noise ? 1.0 : 0.0)) + 4.0 * B * H * W * (lowres_c ? 2.0 : 1.0), s);
+  switch (rule) {
+    case DT_RULE_ENGINE: cfg_update_kernel<DT_RULE_ENGINE, true><<<blocks, 256, 0, s>>>(a); break;
+    case DT_RULE_PSAMPLE: cfg_update_kernel<DT_RULE_PSAMPLE, true><<<blocks, 256, 0, s>>>(a); break;
+    case DT_RULE_MANAGER: cfg_update_kernel<DT_RULE_MANAGER, true><<<blocks, 256, 0, s>>>(a); break;
     default: return DT_E_ARG;
   }
   DT_LAUNCH_CHECK();

@@ -122,6 +122,10 @@ class UNetHandle:
         check(self.lib.dt_unet_set_precision(self.h, int(mode)), "dt_unet_set_precision")
         self._tuned.clear()
 
+    def set_head_fusion(self, on):
+        """Test hook (dt_unet_set_head_fusion): off = separate head launch, dec1's output is materialised."""
+        check(self.lib.dt_unet_set_head_fusion(self.h, int(bool(on))), "dt_unet_set_head_fusion")
+
     def autotune(self, batch_total, H, W):
         """Measure tile / tap-split candidates for this forward shape once and keep the fastest (dt_unet_autotune)."""
         key = (batch_total, H, W)

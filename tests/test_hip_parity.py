@@ -78,12 +78,16 @@ def test_unet_block_activations_golden(golden, gpu_models):
     x = seeded_noise(c["seed"], (c["b"], 3, c["h"], c["h"])).to(DEV)
     y = m(x, torch.tensor([c["t"]] * c["b"], device=DEV), torch.ones(c["b"], 1, device=DEV))
     h = engine.UNetHandle.for_module(m)
+    h.set_head_fusion(False)                               # dec1's output is only materialised without the fused head
+    y_unfused = m(x.to(DEV), torch.tensor([c["t"]] * c["b"]).to(DEV), torch.ones(c["b"], 1, device=DEV))
     for j, name in enumerate(unet_ref.BLOCKS):
         want = arrays["act_" + name]                       # NCHW
         got = h.debug_activation(c["b"], c["h"], c["h"], j).cpu().numpy()   # NHWC, padded channels
         assert_close(got[..., : want.shape[1]].transpose(0, 3, 1, 2), want, what=name)
         assert not got[..., want.shape[1]:].any(), f"{name}: channel padding must stay zero"
-    assert_close(y.cpu().numpy(), arrays["act_out"], what="eps")
+    h.set_head_fusion(True)
+    assert_close(y.cpu().numpy(), arrays["act_out"], what="eps (head in dec1.conv2's epilogue)")
+    assert_close(y_unfused.cpu().numpy(), arrays["act_out"], what="eps (separate head launch)")
 
 
 @pytest.mark.parametrize("sf", [0.05, 0.3, 0.4, 0.75])
