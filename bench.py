@@ -230,13 +230,18 @@ class PairWorkload:
         for i, ps in enumerate(self.parts):
             if len(ps) > 1:                      # reassemble [T+1, B, E] for the pairwise metrics
                 torch.cat(self.part_traj[i], dim=1, out=self.traj[i])
+        t_gpu0 = time.perf_counter() if os.environ.get("DT_BENCH_TIMING") else 0.0
         sums = eng.device_metric_sums(self.traj[0], self.traj[1])          # [B, T+1, 4] float64
         w1 = eng.device_wasserstein(self.traj[0], self.traj[1], self.w_index, self.w_rows)   # [B, T+1] float64
         local = torch.cat([sums.reshape(self.B, -1), w1], dim=1)
         full = all_gather_rows(local, counts, dim=0) if world > 1 else local
         host = full.cpu().numpy()                                          # syncs the stream
         n = T + 1
+        t_host0 = time.perf_counter() if t_gpu0 else 0.0
         vals = eng.batch_scalar_metrics(host[:, : 4 * n].reshape(-1, n, 4), host[:, 4 * n:], H * H, self.E)
+        if t_gpu0:
+            sys.stderr.write(f"[bench timing] launch threads joined -> results on host {1e3 * (t_host0 - t_gpu0):.2f} ms, "
+                             f"host post-transform {1e3 * (time.perf_counter() - t_host0):.2f} ms\n")
         if self.choices is None:
             self.choices = {f"sf={sf}": [list(c) for c in ps[0][0].conv_choices(2 * (ps[0][1][1] - ps[0][1][0]), H, H)]
                             for sf, ps in zip(self.spec["sf"], self.parts)}
@@ -490,11 +495,17 @@ def main():
         vals = wl.step(world, counts)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, no instrumentation
     barrier()
+    if os.environ.get("DT_BENCH_MARKERS") == "1":          # rocprofv3 runs: bracket the timed steps (profiles/collect_r02.sh)
+        _hip.profile_marker(1)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         vals = wl.step(world, counts)
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("DT_BENCH_MARKERS") == "1":
+        _hip.profile_marker(2)
+        torch.cuda.synchronize()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

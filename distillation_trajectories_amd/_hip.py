@@ -55,6 +55,7 @@ SIGNATURES = {
     "dt_traj_resampled_distance": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dt_pair_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dt_traj_sample_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dt_profile_marker": (c_int, [c_int, c_void_p]),
     "dt_profile_begin": (c_int, []),
     "dt_profile_end": (c_int, []),
     "dt_profile_class_count": (c_int, []),
@@ -104,6 +105,11 @@ def ptr(t):
 def stream_ptr():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_marker(marker_id):
+    """Empty, recognisably named kernel on the current stream (brackets a region for external profilers)."""
+    check(load().dt_profile_marker(int(marker_id), stream_ptr()), "dt_profile_marker")
 
 
 def profile_begin():

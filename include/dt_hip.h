@@ -216,6 +216,9 @@ int dt_traj_sample_mean(const float *traj_dev, int n, int B, int E, float *out_d
  * the launch stream.  dt_profile_read (after the stream has been synchronised) sums, per kernel
  * class, the launches, the event-measured milliseconds and the ALGORITHMIC flops / bytes of those
  * launches (real channel counts, no padding; what the reference's own ops would count). */
+/* launches the empty kernel `profile_marker_kernel` on the stream: rocprofv3 kernel traces of a run can then be cut to
+ * the region between two markers (profiles/summarize_pmc.py keeps the timed steps and drops the autotuner's trials) */
+int dt_profile_marker(int id, void *stream);
 int dt_profile_begin(void);
 int dt_profile_end(void);
 int dt_profile_class_count(void);

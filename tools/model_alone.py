@@ -5,11 +5,13 @@ import torch
 import bench
 from distillation_trajectories_amd._hip import RULE_PSAMPLE
 torch.cuda.set_device(0)
-wl = bench.Workload(torch.device("cuda:0"), 0, 256)
+spec = bench.CONFIGS[1]
+wl = bench.PairWorkload(spec, torch.device("cuda:0"), 0, spec["batch"])
 def run(i):
-    (h, (lo, hi)), tb, traj = wl.parts[i][0], wl.tb[i], wl.part_traj[i][0]
+    (h, (lo, hi)), traj = wl.parts[i][0], wl.part_traj[i][0]
+    tb = h.time_bias_general(wl.tb_t, wl.tb_cond, wl.tb_present, 2 * wl.T)
     traj[0].copy_(wl.x_T[lo:hi])
-    h.sample(RULE_PSAMPLE, traj, bench.H, bench.H, tb, 2, wl.coef, wl.has_noise, z=wl.z, z_shift=wl.z_shift, w_scalar=bench.GUIDANCE)
+    h.sample(RULE_PSAMPLE, traj, wl.H, wl.H, tb, 2, wl.coef, wl.has_noise, z=wl.z, z_shift=wl.z_shift, w_scalar=spec["guidance"])
 def timed(fn, reps=3):
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
