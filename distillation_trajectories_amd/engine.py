@@ -40,6 +40,39 @@ def sinusoid_frequencies(dim):
     return torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1 + 1e-8)))
 
 
+class _TuneCache:
+    """Optional on-disk record of autotuned launch plans (env DT_TUNE_CACHE = a JSON file).  The autotuner's picks between
+    near-equal candidates differ from run to run, which changes results at fp32-rounding level and makes profiler passes
+    of 'the same command' launch different kernels; with a cache every process replays the plan the first one measured."""
+
+    @staticmethod
+    def path():
+        return os.environ.get("DT_TUNE_CACHE") or None
+
+    @staticmethod
+    def load():
+        import json
+        p = _TuneCache.path()
+        if not p:
+            return None
+        try:
+            with open(p) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            return {}
+
+    @staticmethod
+    def store(key, plan):
+        import json
+        p = _TuneCache.path()
+        cache = _TuneCache.load() or {}
+        cache[key] = plan
+        tmp = f"{p}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(cache, f)
+        os.replace(tmp, p)
+
+
 class UNetHandle:
     """Owns one ``dt_unet`` (packed weights in HBM) built from a module's state_dict."""
 
@@ -131,11 +164,30 @@ class UNetHandle:
         key = (batch_total, H, W)
         if key in self._tuned:
             return
+        cache_key = f"{self.channels}:{self.temb_dim}:{','.join(map(str, self.dims))}:{batch_total}x{H}x{W}"
+        cache = _TuneCache.load()
+        if cache is not None and cache_key in cache:
+            # a recorded plan (DT_TUNE_CACHE=file): every process / profiler pass then launches the same kernels
+            for block, slot, bm, bn, sp, prec, fuse in cache[cache_key]:
+                check(self.lib.dt_unet_set_conv_choice(self.h, batch_total, H, W, block, slot, bm, bn, sp, prec, fuse),
+                      "dt_unet_set_conv_choice")
+            self._tuned.add(key)
+            return
         ws = self.workspace(batch_total, H, W)
         with torch.cuda.device(self.device):
             check(self.lib.dt_unet_autotune(self.h, batch_total, H, W, ptr(ws), c_size_t(ws.numel()), stream_ptr()),
                   "dt_unet_autotune")
         self._tuned.add(key)
+        if cache is not None:
+            plan = []
+            for j in range(8):
+                for slot in range(3):
+                    bm, bn, sp, pr, tu = c_int(), c_int(), c_int(), c_int(), c_int()
+                    check(self.lib.dt_unet_conv_choice(self.h, batch_total, H, W, j, slot, ctypes.byref(bm), ctypes.byref(bn),
+                                                       ctypes.byref(sp), ctypes.byref(pr), ctypes.byref(tu)), "dt_unet_conv_choice")
+                    if bm.value:
+                        plan.append([j, slot, bm.value, bn.value, sp.value, pr.value & 7, 1 if pr.value & 8 else 0])
+            _TuneCache.store(cache_key, plan)
 
     def set_conv_choice(self, batch_total, H, W, block, slot, bm, bn, splits=1, prec=1, fuse=0):
         """Pin one convolution's launch choice for this forward shape (dt_unet_set_conv_choice)."""
