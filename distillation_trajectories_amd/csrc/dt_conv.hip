@@ -15,6 +15,8 @@
 // identically for A and B, so the sum over k is complete and the result layout is the standard one:
 // acc register r of lane l = D[row (r&3)+8*(r>>2)+4*(l>>5)][col l&31], i.e. a register is a 128-B run
 // of consecutive channels for two pixel rows -> coalesced NHWC stores.
+#include <cstdlib>
+
 #include "dt_conv_epilogue.h"
 
 namespace dt {

@@ -45,9 +45,15 @@ constexpr int epilogue_stage_floats() { return 64 * (BN + 4); }
 // and the mode flags are tested per pass, not per element.
 //
 // `stage` is any LDS the kernel no longer needs (>= epilogue_stage_floats<BN>() floats); every wave of the
-// workgroup must call this (it contains barriers).  Modes: split-K slab store (raw sums), or
+// workgroup must call this (it contains barriers).  Per row m and channel n:
 //   v = in2 ? acc + bias2 : relu?(acc * scale + shift);  v += time bias row;  v += residual;  v += x3 skip;
-//   out = v;  pool_out = 2x2 max of v (32-row tiles hold whole row pairs for W <= 16).
+//   out = v;  pool_out = 2x2 max of v (32-row tiles hold whole row pairs for W <= 16);  head_out = 1x1 head of v.
+//
+// Split-K (p.splits > 1, grid.z slices of the K walk): the raw sums go to this slice's slab and splitk_epilogue_kernel
+// sums the slabs in z order in a second launch.  (Finishing inside the launch -- write-through slab stores, a ticket
+// counter per tile, the last workgroup to arrive sums the slabs behind an agent-scope acquire -- was built and measured
+// in round 2: bit-identical results, the same time at batch 256 (the acquire + the serial slab reads of one workgroup
+// per tile cost what the second launch costs) and 38 % slower at batch 8, where tiles are few and splits deep.)
 template <int MI, int NI>
 __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI], float *stage, int m0, int n0, int wm, int wn,
                                      int half, int l31) {
@@ -55,9 +61,14 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
   const int tid = threadIdx.x;
   const int HW = p.H * p.W;
   const bool slab_mode = p.splits > 1;
-  float *slab = slab_mode ? p.slab + (size_t)blockIdx.z * p.M * p.cout_p : nullptr;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+  const size_t slab_stride = (size_t)p.M * p.cout_p;
+  // ---- this thread's units of a pass: row = tid / C4 + k * (256 / C4), four consecutive channels
+  const int c4 = tid % C4, row0 = tid / C4;
+  const int n = n0 + c4 * 4;
+  const bool n_ok = n < p.cout_p;
+  const int nn = n_ok ? n : 0;
+  auto unit_row = [&](int mi, int k) { const int row = row0 + k * (256 / C4); return m0 + (row >> 5) * (MI * 32) + mi * 32 + (row & 31); };
+  auto to_stage = [&](int mi) __attribute__((always_inline)) {
     __syncthreads();                                   // the main loop (or the previous pass) is done with this LDS
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -67,27 +78,36 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
         stage[(wm * 32 + L) * P + wn * (NI * 32) + ni * 32 + l31] = acc[mi][ni][r];
       }
     __syncthreads();
-    // ---- this thread's units: row = tid / C4 + k * (256 / C4), four consecutive channels
-    const int c4 = tid % C4, row0 = tid / C4;
-    const int n = n0 + c4 * 4;
-    const bool n_ok = n < p.cout_p;
+  };
+
+  if (slab_mode) {
+    float *slab = p.slab + (size_t)blockIdx.z * slab_stride;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      to_stage(mi);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int m = unit_row(mi, k);
+        if (n_ok && m < p.M)
+          *reinterpret_cast<f32x4 *>(slab + (size_t)m * p.cout_p + n) = *reinterpret_cast<const f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4);
+      }
+    }
+    return;                                            // splitk_epilogue_kernel finishes the layer
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
     f32x4 v[U];
     int mrow[U];
     bool ok[U];
+    to_stage(mi);
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-      const int row = row0 + k * (256 / C4);
-      mrow[k] = m0 + (row >> 5) * (MI * 32) + mi * 32 + (row & 31);
+      mrow[k] = unit_row(mi, k);
       ok[k] = n_ok && mrow[k] < p.M;
-      v[k] = *reinterpret_cast<const f32x4 *>(stage + row * P + c4 * 4);
     }
-    if (slab_mode) {
 #pragma unroll
-      for (int k = 0; k < U; ++k)
-        if (ok[k]) *reinterpret_cast<f32x4 *>(slab + (size_t)mrow[k] * p.cout_p + n) = v[k];
-      continue;
-    }
-    const int nn = n_ok ? n : 0;
+    for (int k = 0; k < U; ++k) v[k] = *reinterpret_cast<const f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4);
     if (p.in2) {
       const f32x4 b2 = *reinterpret_cast<const f32x4 *>(p.bias2 + nn);   // BN/ReLU were applied before the skip walk
 #pragma unroll

@@ -642,3 +642,54 @@ def test_next_row_fid_sampler(golden, gpu_models):
     assert_close(got.cpu().numpy(), arrays["fid_loop"], rtol=1e-4, atol=1e-4, what="fid p_sample_loop")
     assert abs(calculate_fid(arrays["fid_feat1"], arrays["fid_feat2"]) - c["fid"]) <= 1e-12 * abs(c["fid"])
     assert calculate_fid(arrays["fid_feat1"][:1], arrays["fid_feat2"]) == 999.0
+
+
+def test_split_k_is_deterministic_under_load(gpu_models):
+    """Every 3x3 layer split along K as deep as it goes: the slabs are summed in z order, so 150 repeated forwards must
+    agree bit for bit with the first one -- also while another model keeps the chip unevenly busy on a second stream;
+    the first result is checked against the oracle."""
+    import threading
+    m, other = gpu_models(1.0), gpu_models(0.5)
+    h, ho = engine.UNetHandle.for_module(m), engine.UNetHandle.for_module(other)
+    B = 37
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, 3, 16, 16, generator=g).to(DEV)
+    tb = h.time_bias([21, 21], [_hip.COND_NONE, _hip.COND_ONE])
+    tbo = ho.time_bias([21, 21], [_hip.COND_NONE, _hip.COND_ONE])
+    h.set_precision(_hip.PREC_AUTO)
+    splits = {}
+    for block in range(1, 8):                       # every 3x3 layer split as deep as its channel count allows
+        for slot in (1, 2):
+            for sp in (8, 4, 2):
+                try:
+                    h.set_conv_choice(2 * B, 16, 16, block, slot, 64 if block in (3, 4, 5) else 128, 64, sp, 3 if block != 4 else 1, 0)
+                    splits[(block, slot)] = sp
+                    break
+                except _hip.HipLibraryError:
+                    continue
+    assert len(splits) >= 10, splits
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = unet_ref.unet_forward(sd, x[:3].cpu(), torch.full((3,), 21), torch.ones(3, 1)).numpy()
+    first = h.forward(x, tb, 2, B, tune=False).clone()
+    assert_close(first[B:B + 3].cpu().numpy(), want, what="split everywhere")
+    stop = threading.Event()
+    side = torch.cuda.Stream()
+
+    def noise_maker():                              # uneven load: bursts of another model's forwards
+        xo = torch.randn(64, 3, 16, 16, device=DEV)
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                for _ in range(3):
+                    ho.forward(xo, tbo, 2, 64, tune=False)
+                side.synchronize()
+    t = threading.Thread(target=noise_maker)
+    t.start()
+    try:
+        for it in range(150):
+            again = h.forward(x, tb, 2, B, tune=False)
+            assert torch.equal(again, first), f"forward {it} differs from the first one"
+    finally:
+        stop.set()
+        t.join()
+    h.set_precision(_hip.PREC_AUTO)
