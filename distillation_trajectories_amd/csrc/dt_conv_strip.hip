@@ -7,7 +7,7 @@
 //      strip row s  <->  pixel m0 - (W+1) + s,      s in [0, BM + 2(W+1))
 // and tap (dy, dx) of output row r reads strip row r + (W+1) + dy*W + dx -- the same LDS image at a shifted row.
 // Taps that fall outside the picture (zero padding, also across picture boundaries inside a tile) read one of
-// sixteen all-zero rows instead (the one with the same bank as the real row would have: no conflicts); validity
+// eight all-zero rows instead (the one with the same bank as the real row would have: no conflicts); validity
 // is a 9-bit mask per fragment row, computed once.
 // Per chunk: one strip load/split/write, then nine steps that only stage the 3 x BN x 16 weight tile of their
 // tap (double buffered) and run 24 MFMAs per wave.  ds_read_b128 stays conflict-free at any shift because the
@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   constexpr int AP = 2;                                            // strip items (row, k-half) per thread
   const int halo = p.W + 1;
   const int R = BM + 2 * halo;                                     // strip rows
-  const int RZ = (R + 7) & ~7;                                     // 16 all-zero rows start here (multiple of 8)
-  const int PLANE_A = (RZ + 16) * 16;
-  __bf16 *As = strip_lds;                                          // [KC][3][RZ+16][16]
+  const int RZ = (R + 7) & ~7;                                     // 8 all-zero rows start here (multiple of 8)
+  const int PLANE_A = (RZ + 8) * 16;
+  __bf16 *As = strip_lds;                                          // [KC][3][RZ+8][16]
   __bf16 *Bs = strip_lds + KC * 3 * PLANE_A;                       // [2][KC][3][BN][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   // ---- prologue: strip of chunk 0, weights of step 0, the zero row
   load_strip(0);
   load_b(ADV_NONE);
-  if (tid < 96 * KC) *reinterpret_cast<u32x4 *>(As + (tid >> 5) * PLANE_A + RZ * 16 + (tid & 31) * 8) = u32x4{0u, 0u, 0u, 0u};
+  if (tid < 48 * KC) *reinterpret_cast<u32x4 *>(As + (tid >> 4) * PLANE_A + RZ * 16 + (tid & 15) * 8) = u32x4{0u, 0u, 0u, 0u};
   write_strip();
   write_b(0);
   __syncthreads();
@@ -219,12 +219,13 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
       int a_e[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        // an out-of-picture tap reads zero row RZ + (srow & 15) at the same physical half: the bank a lane hits is
+        // an out-of-picture tap reads zero row RZ + (srow & 7) at the same physical half (a row's 16-B slot in the 256-B
+        // bank row depends on srow & 7 and, through the half swap, on bit 3 -- which `half ^ ...` below keeps): the bank a lane hits is
         // the one its in-picture read would hit, so any mix of the two stays conflict-free
         int row0 = a_row[mi];
         asm volatile("" : "+v"(row0));       // keeps the nine taps' addresses from being hoisted out of the chunk loop (18+ VGPRs)
         const int srow = row0 + shift;
-        const int lrow = ((a_mask[mi] >> tt) & 1u) ? srow : RZ + (srow & 15);
+        const int lrow = ((a_mask[mi] >> tt) & 1u) ? srow : RZ + (srow & 7);
         a_e[mi] = lrow * 16 + ((half ^ ((srow >> 3) & 1)) << 3);
       }
 #pragma unroll
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
 
 static size_t strip_lds_bytes(int W, int bm, int bn, int kc) {
   const int R = bm + 2 * (W + 1);
-  const size_t loop = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 16) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
+  const size_t loop = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 8) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
   const size_t stage = (size_t)64 * (bn + 4) * sizeof(float);      // the staged epilogue reuses the same LDS
   return loop > stage ? loop : stage;
 }
