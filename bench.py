@@ -179,7 +179,9 @@ class PairWorkload:
         torch.cuda.synchronize()
         self.choices = None
         self.concurrent = concurrent
-        self.streams = [[torch.cuda.Stream(device=device) for _ in ps] for ps in self.parts]
+        # DT_BENCH_PRIO=t,s: HIP stream priorities of the teacher / student loops (lower = more urgent; default equal)
+        prio = [int(v) for v in os.environ.get("DT_BENCH_PRIO", "0,0").split(",")]
+        self.streams = [[torch.cuda.Stream(device=device, priority=prio[i]) for _ in ps] for i, ps in enumerate(self.parts)]
         self.units_per_step = 2 * batch * T
 
     def describe(self, world):

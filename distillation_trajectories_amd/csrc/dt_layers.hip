@@ -117,42 +117,41 @@ int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hi
 }
 
 // out[b][y][x][0:c1p] = bilinear_x2(lo[b]), out[...][c1p:c1p+c2p] = skip[b][y][x]  (torch.cat dim=1)
-__global__ void upcat_kernel(const float4 *__restrict__ lo, const float4 *__restrict__ skip, float4 *__restrict__ out,
-                             int Bt, int h, int w, int c1q, int c2q) {
-  const int H = 2 * h, W = 2 * w, cq = c1q + c2q;
-  const int cw = skip ? cq : c1q;                 // skip == nullptr: only the upsampled channels are written
-  const size_t total = (size_t)Bt * H * W * cw;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = i % cw;
-    size_t r = i / cw;
-    const size_t pixel = r;
-    const int x = r % W; r /= W;
-    const int y = r % H;
-    const int b = r / H;
+// 32-bit index math (the launcher checks the element count), one float4 of channels per thread.
+__global__ __launch_bounds__(256) void upcat_kernel(const float4 *__restrict__ lo, const float4 *__restrict__ skip,
+                                                    float4 *__restrict__ out, int Bt, int h, int w, int c1q, int c2q) {
+  const unsigned H = 2 * h, W = 2 * w, cq = c1q + c2q;
+  const unsigned cw = skip ? cq : (unsigned)c1q;  // skip == nullptr: only the upsampled channels are written
+  const unsigned total = (unsigned)Bt * H * W * cw;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned pixel = i / cw, c = i - pixel * cw;
+    const unsigned row = pixel / W, x = pixel - row * W;
+    const unsigned b = row / H, y = row - b * H;
     float4 o;
-    if (c >= c1q) {
-      o = skip[(((size_t)b * H + y) * W + x) * c2q + (c - c1q)];
+    if (c >= (unsigned)c1q) {
+      o = skip[(size_t)pixel * c2q + (c - c1q)];
     } else {
       int y0, y1, x0, x1;
       float wy0, wy1, wx0, wx1;
-      bilinear_src(y, h, H, y0, y1, wy0, wy1);
-      bilinear_src(x, w, W, x0, x1, wx0, wx1);
+      bilinear_src((int)y, h, (int)H, y0, y1, wy0, wy1);
+      bilinear_src((int)x, w, (int)W, x0, x1, wx0, wx1);
       const float4 *base = lo + (size_t)b * h * w * c1q + c;
-      const float4 v00 = base[((size_t)y0 * w + x0) * c1q], v01 = base[((size_t)y0 * w + x1) * c1q];
-      const float4 v10 = base[((size_t)y1 * w + x0) * c1q], v11 = base[((size_t)y1 * w + x1) * c1q];
+      const float4 v00 = base[(y0 * w + x0) * c1q], v01 = base[(y0 * w + x1) * c1q];
+      const float4 v10 = base[(y1 * w + x0) * c1q], v11 = base[(y1 * w + x1) * c1q];
       o.x = wy0 * (wx0 * v00.x + wx1 * v01.x) + wy1 * (wx0 * v10.x + wx1 * v11.x);
       o.y = wy0 * (wx0 * v00.y + wx1 * v01.y) + wy1 * (wx0 * v10.y + wx1 * v11.y);
       o.z = wy0 * (wx0 * v00.z + wx1 * v01.z) + wy1 * (wx0 * v10.z + wx1 * v11.z);
       o.w = wy0 * (wx0 * v00.w + wx1 * v01.w) + wy1 * (wx0 * v10.w + wx1 * v11.w);
     }
-    out[pixel * cq + c] = o;
+    out[(size_t)pixel * cq + c] = o;
   }
 }
 
 int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p,
                  hipStream_t s) {
   const size_t total = (size_t)Bt * 4 * h * w * ((c1p + (skip ? c2p : 0)) / 4);
-  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  if (total >= (1ull << 32)) return DT_E_SHAPE;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   ProfileScope prof(KC_UPCAT, 0.0, 4.0 * Bt * h * w * (c1p + 4.0 * c1p + (skip ? 8.0 * c2p : 0.0)), s);
   upcat_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const float4 *>(lo), reinterpret_cast<const float4 *>(skip),
                                        reinterpret_cast<float4 *>(out), Bt, h, w, c1p / 4, c2p / 4);

@@ -72,6 +72,26 @@ def counters(pass_dir):
     return acc
 
 
+def launch_gaps(pass_dir):
+    """Idle time between consecutive dispatches of the timed window (one stream in --serial runs): start[i+1] - end[i]."""
+    f, win = find(pass_dir, "kernel_trace.csv"), timed_window(pass_dir)
+    if not f or not win:
+        return None
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), klass(r["Kernel_Name"]) or r["Kernel_Name"])
+               for r in csv.DictReader(open(f)) if win[0] < int(r["Dispatch_Id"]) < win[1])
+    gaps = sorted(max(0, d[i + 1][0] - d[i][1]) for i in range(len(d) - 1))
+    busy = sum(e - s0 for s0, e, _ in d)
+    span = d[-1][1] - d[0][0]
+    q = lambda x: gaps[int(x * (len(gaps) - 1))]
+    return {"dispatches": len(d), "span_ms": span / 1e6, "kernel_busy_ms": busy / 1e6, "idle_between_kernels_ms": (span - busy) / 1e6,
+            "gap_ns": {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "mean": sum(gaps) / len(gaps)}, "method": METHOD}
+
+
+gaps = launch_gaps(tag + "_stats")
+if gaps:
+    json.dump(gaps, open(os.path.join(root, "profiles", f"{tag}_launch_gaps.json"), "w"), indent=1)
+    print(f"{tag}_launch_gaps.json:", gaps["gap_ns"], f"idle {gaps['idle_between_kernels_ms']:.2f} of {gaps['span_ms']:.2f} ms")
+
 rows = kernel_stats(tag + "_stats")
 if rows:
     with open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"), "w", newline="") as f:

@@ -125,6 +125,72 @@ void run(const char *name, float *out, const u32x4 *src, long long *clk, int blo
          ms, ms * 1e6 / iters / (blocks / 256), (double)h[0] / iters, h[0] / (h[1] * 0.01), (double)blocks * 4 * iters * 24 * 2.0 * 32 * 32 * 16 / ms / 1e9);
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// MODE16: 0 bare 48 x 16x16x32 | 1 + 20 ds_read_b128 (K-concatenated plane pairs: 8 A + 12 B fragments) pipelined | 2 + 12 reads
+template <int MODE16>
+__global__ __launch_bounds__(256, 2) void k16(float *out, long long *clk, int iters) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[24 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 24 * 1024 / 8; i += 256) {
+    bf16x8 v;
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(((i * 8 + j) * 2654435761u >> 20) * (1.0f / 4096) - 0.5f);
+    *reinterpret_cast<bf16x8 *>(lds + i * 8) = v;
+  }
+  __syncthreads();
+  constexpr int NA = 8, NB = 12;
+  bf16x8 fa[2][NA], fb[2][NB];
+  const int r15 = lane & 15, g = lane >> 4;
+  const int base = r15 * 16 + (((g & 1) ^ ((r15 >> 3) & 1)) << 3) + (g >> 1) * 4096;
+  for (int s = 0; s < 2; ++s) {
+    for (int i = 0; i < NA; ++i) fa[s][i] = *reinterpret_cast<const bf16x8 *>(lds + base + (s * NA + i) * 256);
+    for (int i = 0; i < NB; ++i) fb[s][i] = *reinterpret_cast<const bf16x8 *>(lds + base + 8192 + (s * NB + i) * 256);
+  }
+  f32x4v acc[4][4] = {};
+  const long long t0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE16 >= 1) {
+      const int a2 = base + ((it & 7) << 8);
+      constexpr int RA = MODE16 == 1 ? NA : 4, RB = MODE16 == 1 ? NB : 8;
+      for (int i = 0; i < RA; ++i) fa[1][i] = *reinterpret_cast<const bf16x8 *>(lds + a2 + i * 256);
+      for (int i = 0; i < RB; ++i) fb[1][i] = *reinterpret_cast<const bf16x8 *>(lds + a2 + 8192 + i * 256);
+    }
+    for (int mi = 0; mi < 4; ++mi)
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4v c = acc[mi][ni];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][2 * mi + 1], fb[0][3 * ni + 1], c, 0, 0, 0);   // [a1|a3].[b3|b1]
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][2 * mi], fb[0][3 * ni], c, 0, 0, 0);           // [a1|a2].[b2|b1]
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][2 * mi], fb[0][3 * ni + 2], c, 0, 0, 0);       // [a1|a2].[b1|b2]
+        acc[mi][ni] = c;
+      }
+    if (MODE16 >= 1) {
+      for (int i = 0; i < NA; ++i) { const bf16x8 t = fa[0][i]; fa[0][i] = fa[1][i]; fa[1][i] = t; }
+      for (int i = 0; i < NB; ++i) { const bf16x8 t = fb[0][i]; fb[0][i] = fb[1][i]; fb[1][i] = t; }
+    }
+  }
+  const long long t1 = clock64(), w1 = wall_clock64();
+  float s = 0.f;
+  for (int mi = 0; mi < 4; ++mi) for (int ni = 0; ni < 4; ++ni) for (int r = 0; r < 4; ++r) s += acc[mi][ni][r];
+  out[blockIdx.x * 256 + tid] = s;
+  if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
+template <int MODE16>
+void run16(const char *name, float *out, long long *clk, int blocks) {
+  const int iters = 4000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  k16<MODE16><<<blocks, 256>>>(out, clk, 2000);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k16<MODE16><<<blocks, 256>>>(out, clk, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  long long h[2]; hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+  printf("%-58s blocks/CU %d: %7.3f ms = %6.0f ns per block of 48 (launch time) | clock64: %5.0f per block, %.0f MHz | %5.0f TF/s bf16\n", name, blocks / 256,
+         ms, ms * 1e6 / iters / (blocks / 256), (double)h[0] / iters, h[0] / (h[1] * 0.01), (double)blocks * 4 * iters * 48 * 2.0 * 16 * 16 * 32 / ms / 1e9);
+}
+
 int main() {
   float *out; long long *clk; u32x4 *src;
   hipMalloc(&out, 1024 * 256 * sizeof(float));
@@ -132,7 +198,13 @@ int main() {
   hipMalloc(&src, 64 * 768 * sizeof(u32x4));
   hipMemset(src, 0x3c, 64 * 768 * sizeof(u32x4));
   for (int blocks = 256; blocks <= 512; blocks += 256) {
+    run16<0>("16x16x32: 48 MFMA, 16 accumulators", out, clk, blocks);
+    run16<1>("16x16x32: + 20 ds_read_b128, pipelined", out, clk, blocks);
+    run16<2>("16x16x32: + 12 ds_read_b128, pipelined", out, clk, blocks);
     run<0>("0: 24 MFMA, 4 accumulators", out, src, clk, blocks);
+    run<6>("6: 32x32x16 pipelined, 12 ds_read_b128", out, src, clk, blocks);
+    run16<0>("16x16x32: 48 MFMA, 16 accumulators (again)", out, clk, blocks);
+    run<0>("0: 24 MFMA, 4 accumulators (again)", out, src, clk, blocks);
     run<4>("4: 24 MFMA, 1 accumulator", out, src, clk, blocks);
     run<5>("5: 24 MFMA, 2 accumulators", out, src, clk, blocks);
     run<1>("1: + 12 ds_read_b128 (unused)", out, src, clk, blocks);
