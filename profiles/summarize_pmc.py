@@ -87,6 +87,30 @@ def launch_gaps(pass_dir):
             "gap_ns": {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "mean": sum(gaps) / len(gaps)}, "method": METHOD}
 
 
+def forward_timelines(pass_dir):
+    """Launch-by-launch listing of one forward + update of each model in the serial loop: dispatches between two
+    consecutive cfg_update launches, the 25th of the first loop (teacher) and the 25th of the second (student)."""
+    f, win = find(pass_dir, "kernel_trace.csv"), timed_window(pass_dir)
+    if not f or not win:
+        return None
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), klass(r["Kernel_Name"]) or r["Kernel_Name"].split("(")[0][-40:])
+               for r in csv.DictReader(open(f)) if win[0] < int(r["Dispatch_Id"]) < win[1])
+    ends = [i for i, x in enumerate(d) if x[2] == "cfg_update_kernel"]
+    out = {}
+    for name, k in (("teacher_forward_25", 24), ("student_forward_25", 74)):
+        if k + 1 >= len(ends):
+            continue
+        seg = d[ends[k] + 1: ends[k + 1] + 1]
+        out[name] = {"launches": len(seg), "span_us": (seg[-1][1] - seg[0][0]) / 1e3, "busy_us": sum(e - s0 for s0, e, _ in seg) / 1e3,
+                     "sequence": [[n, round((e - s0) / 1e3, 1)] for s0, e, n in seg]}
+    return out
+
+
+tl = forward_timelines(tag + "_stats")
+if tl:
+    json.dump(tl, open(os.path.join(root, "profiles", f"{tag}_forward_timeline.json"), "w"), indent=1)
+    print(f"{tag}_forward_timeline.json:", {k: (v["launches"], round(v["span_us"], 1)) for k, v in tl.items()})
+
 gaps = launch_gaps(tag + "_stats")
 if gaps:
     json.dump(gaps, open(os.path.join(root, "profiles", f"{tag}_launch_gaps.json"), "w"), indent=1)
