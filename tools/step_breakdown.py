@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 torch.cuda.set_device(0)
-wl = bench.Workload(torch.device("cuda:0"), 0, 256)
+spec = bench.CONFIGS[1]
+wl = bench.PairWorkload(spec, torch.device("cuda:0"), 0, spec["batch"])
 wl.step(1, None); torch.cuda.synchronize()
 import types
 eng = wl.engine
