@@ -399,3 +399,28 @@ def test_unchanged_caller_flow_with_aliases(models, tmp_path, monkeypatch):
                 assert set(cell) == {"path_length_similarity", "trajectory_mse", "mean_directional_consistency", "distribution_similarity"}
     finally:
         pkg.remove_aliases()
+
+
+def test_two_ranks_shard_the_grid_like_one(tmp_path):
+    """configs[3] in miniature on one GPU: bench.py's own launcher starts 2 ranks (gloo stands in for RCCL so that both
+    can share this GPU), each runs its sample shard of the 11-size x 4-scale grid on the HIP path, the metric rows are
+    all-gathered, and the gathered cells must equal those of ONE rank running all the samples."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(gpus, batch):
+        res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "2", "--gpus", str(gpus), "--batch", str(batch),
+                              "--steps", "1", "--warmup", "0", "--no-profile", "--no-cpu-baseline"], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    two, one = run(2, 3), run(1, 6)
+    assert two["n_gpus"] == 2 and [r["rank"] for r in two["ranks"]] == [0, 1] and one["n_gpus"] == 1
+    assert two["metric_check"]["cells"] == one["metric_check"]["cells"] == 11 * 4 * 6
+    a, b = two["metric_check"]["path_length_similarity_sf0.5_gs3"], one["metric_check"]["path_length_similarity_sf0.5_gs3"]
+    assert abs(a - b) <= 1e-6 * abs(b), (a, b)
