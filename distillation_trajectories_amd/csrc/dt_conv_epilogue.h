@@ -29,10 +29,10 @@ __device__ inline void split8(const f32x4 lo, const f32x4 hi, bf16x8 &p1, bf16x8
   }
 }
 
-// floats of LDS the staged epilogue needs for a BN-column tile: 64 rows (one 32-row accumulator tile of each
-// wave row) at a pitch of BN + 4 floats
-template <int BN>
-constexpr int epilogue_stage_floats() { return 64 * (BN + 4); }
+// floats of LDS the staged epilogue needs for a BN-column tile: WM * 32 rows (one 32-row accumulator tile of each
+// wave row; the four waves sit WM x 4/WM over the tile) at a pitch of BN + 4 floats
+template <int BN, int WM = 2>
+constexpr int epilogue_stage_floats() { return WM * 32 * (BN + 4); }
 
 // Epilogue of every convolution kernel, staged through LDS.
 //
@@ -40,7 +40,7 @@ constexpr int epilogue_stage_floats() { return 64 * (BN + 4); }
 // side inputs (residual, time bias) load the same way: measured per-workgroup timelines (tools/block_timeline.py)
 // put such an epilogue at 14 us for a 128 x 128 tile on an idle chip and 28-35 us with a residual or the fused pool
 // (one exposed memory latency per accumulator register).  Here a 32-row accumulator tile of each wave row goes
-// through LDS once ([64][BN + 4] floats, conflict-free both ways) and comes back as float4 per lane with a whole
+// through LDS once ([WM * 32][BN + 4] floats, conflict-free both ways) and comes back as float4 per lane with a whole
 // row segment per 32 lanes: every side input is one batched float4 load per unit, every store is 16 bytes per lane,
 // and the mode flags are tested per pass, not per element.
 //
@@ -54,10 +54,10 @@ constexpr int epilogue_stage_floats() { return 64 * (BN + 4); }
 // counter per tile, the last workgroup to arrive sums the slabs behind an agent-scope acquire -- was built and measured
 // in round 2: bit-identical results, the same time at batch 256 (the acquire + the serial slab reads of one workgroup
 // per tile cost what the second launch costs) and 38 % slower at batch 8, where tiles are few and splits deep.)
-template <int MI, int NI>
+template <int MI, int NI, int WM = 2>
 __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI], float *stage, int m0, int n0, int wm, int wn,
                                      int half, int l31) {
-  constexpr int BN = NI * 64, P = BN + 4, C4 = BN / 4, U = C4 / 4;   // U float4 units per thread and pass
+  constexpr int BN = NI * 32 * (4 / WM), P = BN + 4, C4 = BN / 4, U = WM * C4 / 8;   // U float4 units per thread and pass
   const int tid = threadIdx.x;
   const int HW = p.H * p.W;
   const bool slab_mode = p.splits > 1;
@@ -207,7 +207,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       __syncthreads();
       const int Wo = p.W >> 1;
 #pragma unroll
-      for (int q = tid; q < 16 * C4; q += 256) {
+      for (int q = tid; q < WM * 8 * C4; q += 256) {
         const int pp = q / C4, qc = q % C4, j = pp & 7;
         const int yy = j / Wo, xx = j - yy * Wo;
         const int L0 = 2 * yy * p.W + 2 * xx;

@@ -5,7 +5,8 @@
 // loads, nine 3-way bf16 splits and nine LDS writes of (nearly) the same pixels.  Here a workgroup keeps the
 // tile's rows PLUS a halo of W+1 pixels on either side in LDS as three bf16 planes:
 //      strip row s  <->  pixel m0 - (W+1) + s,      s in [0, BM + 2(W+1))
-// and tap (dy, dx) of output row r reads strip row r + (W+1) + dy*W + dx -- the same LDS image at a shifted row.
+// and tap (dy, dx) of output row r reads strip row r + (W+1) + dy*W + dx -- the same LDS image at a shifted row
+// (halo W instead of W+1 when the tile covers whole picture rows, see strip_halo).
 // Taps that fall outside the picture (zero padding, also across picture boundaries inside a tile) read one of
 // eight all-zero rows instead (the one with the same bank as the real row would have: no conflicts); validity
 // is a 9-bit mask per fragment row, computed once.
@@ -28,17 +29,24 @@ namespace dt {
 
 extern __shared__ __attribute__((aligned(16))) __bf16 strip_lds[];
 
+// Halo rows either side of the tile.  The corner taps reach W + 1 pixels back / ahead; when the tile starts at x = 0 and
+// ends at x = W - 1 (BM a multiple of W) those two reads are out-of-picture taps of the first / last row and go to the
+// zero rows anyway, so W rows are enough -- which is what lets the K = 32 tile fit twice per CU at W = 16.
+__host__ __device__ inline int strip_halo(int W, int bm) { return bm % W == 0 ? W : W + 1; }
+
 // ABL != 0: timing experiments (wrong results): 1 no per-tap barrier, 2 no weight staging, 3 no MFMA,
 // 4 no fragment reads after the first step, 5 no strip re-staging
 // KC = 16-channel chunks staged and multiplied per step (1 or 2): KC = 2 halves the barriers and doubles the
 // MFMAs between them at twice the LDS footprint and staging registers (2 waves/SIMD instead of 3).
 template <int BM, int BN, int ABL = 0, int KC = 1>
 __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel(const ConvParams p) {
-  constexpr int WN = 2, NT = 256;
-  constexpr int MI = BM / 64, NI = BN / 64;
+  // four waves: 2 x 2 over the tile, or 4 x 1 for the 256 x 64 tile (a 64 x 64 wave tile -- 12 fragment reads per 24
+  // MFMAs, like the 128 x 128 tile -- for layers with 64 output channels, where 128 x 64 leaves each wave 64 x 32)
+  constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, NT = 256;
+  constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
   constexpr int PLANE_B = BN * 16, STAGE_B = 3 * PLANE_B;         // bf16 elements
-  constexpr int AP = 2;                                            // strip items (row, k-half) per thread
-  const int halo = p.W + 1;
+  constexpr int AP = BM == 256 ? 3 : 2;                            // strip items (row, k-half) per thread
+  const int halo = strip_halo(p.W, BM);
   const int R = BM + 2 * halo;                                     // strip rows
   const int RZ = (R + 7) & ~7;                                     // 8 all-zero rows start here (multiple of 8)
   const int PLANE_A = (RZ + 8) * 16;
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   for (int ch = n_main; ch < n_chunks; ++ch)                       // fused 1x1 skip walk: centre tap only
     do_step(std::integral_constant<int, 4>{}, ch, true, true, ch + 1 < n_chunks, ADV_SKIP);
   const long long tl1 = p.ablate == 8 ? wall_clock64() : 0;
-  conv_epilogue<MI, NI>(p, acc, reinterpret_cast<float *>(strip_lds), m0, n0, wm, wn, half, l31);
+  conv_epilogue<MI, NI, WM>(p, acc, reinterpret_cast<float *>(strip_lds), m0, n0, wm, wn, half, l31);
   if (ABL == 9) {                          // per-wave phase sums (cycles) + step count into the unused split-K slab
     if (lane == 0) {
       unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.slab) + 8 * (4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + wave);
@@ -323,21 +331,23 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
 }
 
 static size_t strip_lds_bytes(int W, int bm, int bn, int kc) {
-  const int R = bm + 2 * (W + 1);
+  const int R = bm + 2 * strip_halo(W, bm);
   const size_t loop = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 8) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
-  const size_t stage = (size_t)64 * (bn + 4) * sizeof(float);      // the staged epilogue reuses the same LDS
+  const size_t stage = (size_t)(bm == 256 ? 128 : 64) * (bn + 4) * sizeof(float);   // the staged epilogue reuses the same LDS
   return loop > stage ? loop : stage;
 }
 
 bool strip_admissible(int W, int bm, int bn, int kc) {
-  if (W + 1 > 64) return false;                                    // 2 strip items per thread cover BM + 2(W+1) <= 256 rows
+  if (W + 1 > 64) return false;                                    // 2 (3) strip items per thread cover BM + 2(W+1) <= 256 (384) rows
+  if (bm == 256 && bn != 64) return false;                         // the 4 x 1 wave layout exists for 64-column tiles only
   return strip_lds_bytes(W, bm, bn, kc) <= (kc == 2 ? 98304u : 65536u);
 }
 
 int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s) {
   if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || (kc != 1 && kc != 2)) return DT_E_ARG;
   if ((p.cin_p >> 4) % (p.splits * kc) || (p.in2 && (p.cin2_p >> 4) % kc)) return DT_E_ARG;
-  if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 strip items per thread cover BM + 2(W+1) <= 256 rows
+  if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 (3) strip items per thread cover BM + 2(W+1) <= 256 (384) rows
+  if (bm == 256 && bn != 64) return DT_E_ARG;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   const size_t lds = strip_lds_bytes(p.W, bm, bn, kc);
   if (p.ablate && p.ablate != 7 && p.ablate != 8 && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
@@ -358,7 +368,8 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
     static std::once_flag attr_once;   // 128x128 needs 80 KB of dynamic LDS; launches come from several host threads
     static int attr_status = DT_OK;
     std::call_once(attr_once, [] {
-      const void *fns[4] = {reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 128, 0, 2>),
+      const void *fns[5] = {reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<256, 64, 0, 2>),
+                            reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 128, 0, 2>),
                             reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 64, 0, 2>),
                             reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 128, 0, 2>),
                             reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 64, 0, 2>)};
@@ -369,7 +380,8 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
     });
     if (attr_status != DT_OK) return attr_status;
     if (lds > 98304) return DT_E_SHAPE;
-    if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128, 0, 2><<<grid, 256, lds, s>>>(p);
+    if (bm == 256) conv_strip_bf16x6_kernel<256, 64, 0, 2><<<grid, 256, lds, s>>>(p);
+    else if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128, 0, 2><<<grid, 256, lds, s>>>(p);
     else if (bm == 128) conv_strip_bf16x6_kernel<128, 64, 0, 2><<<grid, 256, lds, s>>>(p);
     else if (bn == 128) conv_strip_bf16x6_kernel<64, 128, 0, 2><<<grid, 256, lds, s>>>(p);
     else conv_strip_bf16x6_kernel<64, 64, 0, 2><<<grid, 256, lds, s>>>(p);
@@ -377,7 +389,8 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
     return DT_OK;
   }
   if (lds > 65536) return DT_E_SHAPE;
-  if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128><<<grid, 256, lds, s>>>(p);
+  if (bm == 256) conv_strip_bf16x6_kernel<256, 64><<<grid, 256, lds, s>>>(p);
+  else if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128><<<grid, 256, lds, s>>>(p);
   else if (bm == 128) conv_strip_bf16x6_kernel<128, 64><<<grid, 256, lds, s>>>(p);
   else if (bn == 128) conv_strip_bf16x6_kernel<64, 128><<<grid, 256, lds, s>>>(p);
   else conv_strip_bf16x6_kernel<64, 64><<<grid, 256, lds, s>>>(p);

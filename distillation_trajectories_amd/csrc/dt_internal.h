@@ -24,7 +24,7 @@ namespace dt {
 enum KernelClass {
   KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
   KC_CONVB_128x128, KC_CONVB_128x64, KC_CONVB_64x128, KC_CONVB_64x64,
-  KC_CONVS_128x128, KC_CONVS_128x64, KC_CONVS_64x128, KC_CONVS_64x64,
+  KC_CONVS_128x128, KC_CONVS_128x64, KC_CONVS_64x128, KC_CONVS_64x64, KC_CONVS_256x64,
   KC_SPLITK_EPILOGUE, KC_FIRST_CONV, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
   KC_WASSERSTEIN, KC_RESAMPLE,
   KC_COUNT

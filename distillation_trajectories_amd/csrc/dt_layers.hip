@@ -11,7 +11,9 @@ namespace dt {
 // 28 + 6 us per teacher forward on 0.1 GFLOP); here a thread keeps the 9C x 4 weights of its channel quad in registers,
 // the zero-bordered image sits in LDS, and the value is computed ONCE per image and stored for every pass with that
 // pass's time-bias row (the passes of a CFG step share x and differ only in the embedding).  HBM-bound on the store.
-template <int C>
+// A thread computes PX consecutive pixels of a picture row from one (PX + 2)-wide window per (channel, dy): the
+// one-pixel form issued 27 LDS reads per stored float4 and was bound by them (25 us for a 67 MB store).
+template <int C, int PX>
 __global__ __launch_bounds__(256) void first_conv_kernel(const float *__restrict__ x, const float *__restrict__ wf,
                                                          const float *__restrict__ scale, const float *__restrict__ shift,
                                                          const float *__restrict__ tb, int tb_stride, int tb_div,
@@ -20,40 +22,64 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float *__restrict
   extern __shared__ float img[];                       // [C][H+2][W+2], zero border
   const int tid = threadIdx.x, b = blockIdx.x / parts, part = blockIdx.x - b * parts;
   const int Wp = W + 2, plane = (H + 2) * Wp, HW = H * W;
+  const int QN = cp >> 2, PPI = 256 / QN;              // channel quads per pixel, pixel groups per sweep of the workgroup
+  const int q = tid % QN, pl = tid / QN;
+  f32x4 w[9 * C];                                      // requested before the image: both latencies overlap
+#pragma unroll
+  for (int k = 0; k < 9 * C; ++k) w[k] = *reinterpret_cast<const f32x4 *>(wf + (size_t)k * cp + q * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + q * 4), sh = *reinterpret_cast<const f32x4 *>(shift + q * 4);
   for (int i = tid; i < C * plane; i += 256) {
     const int c = i / plane, r = i - c * plane;
     const int y = r / Wp - 1, xx = r - (y + 1) * Wp - 1;
     img[i] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[((size_t)(b * C + c) * H + y) * W + xx] : 0.f;
   }
   __syncthreads();
-  const int QN = cp >> 2, PPI = 256 / QN;              // channel quads per pixel, pixels per sweep of the workgroup
-  const int q = tid % QN, pl = tid / QN;
   if (pl >= PPI) return;
-  f32x4 w[9 * C];
+  const int GW = W / PX, G = H * GW;                   // groups of PX pixels along x (the launcher picks PX | W)
+  const int per = (G + parts - 1) / parts;
+  const int hi = (part + 1) * per < G ? (part + 1) * per : G;
+  for (int g = part * per + pl; g < hi; g += PPI) {
+    const int y = g / GW, x0 = (g - y * GW) * PX;
+    f32x4 acc[PX];
 #pragma unroll
-  for (int k = 0; k < 9 * C; ++k) w[k] = *reinterpret_cast<const f32x4 *>(wf + (size_t)k * cp + q * 4);
-  const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + q * 4), sh = *reinterpret_cast<const f32x4 *>(shift + q * 4);
-  const int per = (HW + parts - 1) / parts;
-  const int hi = (part + 1) * per < HW ? (part + 1) * per : HW;
-  for (int pix = part * per + pl; pix < hi; pix += PPI) {
-    const int y = pix / W, xx = pix - y * W;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int px = 0; px < PX; ++px) acc[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // per pixel the accumulation order is (channel, dy, dx), one fma per term: the order of the one-pixel form
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float v = img[c * plane + (y + t / 3) * Wp + xx + t % 3];
+      for (int dy = 0; dy < 3; ++dy) {
+        float v[PX + 2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(v, w[c * 9 + t][e], acc[e]);
+        for (int j = 0; j < PX + 2; ++j) v[j] = img[c * plane + (y + dy) * Wp + x0 + j];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int px = 0; px < PX; ++px)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[px][e] = fmaf(v[px + dx], w[c * 9 + dy * 3 + dx][e], acc[px][e]);
       }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e] * sc[e] + sh[e], 0.f);
+    for (int px = 0; px < PX; ++px)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[px][e] = fmaxf(acc[px][e] * sc[e] + sh[e], 0.f);
+    const int pix = y * W + x0;
     for (int pass = 0; pass < n_pass; ++pass) {
       const int bt = pass * B + b;
       const f32x4 t = *reinterpret_cast<const f32x4 *>(tb + (size_t)(bt / tb_div) * tb_stride + q * 4);
-      *reinterpret_cast<f32x4 *>(out + ((size_t)bt * HW + pix) * cp + q * 4) = acc + t;
+#pragma unroll
+      for (int px = 0; px < PX; ++px)
+        *reinterpret_cast<f32x4 *>(out + ((size_t)bt * HW + pix + px) * cp + q * 4) = acc[px] + t;
     }
   }
+}
+
+template <int PX>
+static void first_conv_dispatch(int C, int grid, size_t lds, hipStream_t s, const float *x, const float *wf, const float *scale,
+                                const float *shift, const float *tb, int tb_stride, int tb_div, float *out, int B, int n_pass,
+                                int H, int W, int cout_p, int parts) {
+  if (C == 1) first_conv_kernel<1, PX><<<grid, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
+  else if (C == 2) first_conv_kernel<2, PX><<<grid, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
+  else first_conv_kernel<3, PX><<<grid, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
 }
 
 int launch_first_conv(const float *x, const float *wf, const float *scale, const float *shift, const float *tb, int tb_stride,
@@ -63,9 +89,8 @@ int launch_first_conv(const float *x, const float *wf, const float *scale, const
   if (lds > 64 * 1024) return DT_E_SHAPE;
   const int parts = B >= 1024 ? 1 : (B >= 256 ? 4 : 8);            // enough workgroups to cover the chip at small batches
   ProfileScope prof(KC_FIRST_CONV, 2.0 * n_pass * B * H * W * (double)cout * 9 * C, 4.0 * B * H * W * (C + (double)n_pass * cout_p), s);
-  if (C == 1) first_conv_kernel<1><<<B * parts, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
-  else if (C == 2) first_conv_kernel<2><<<B * parts, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
-  else first_conv_kernel<3><<<B * parts, 256, lds, s>>>(x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
+  if (W % 4 == 0) first_conv_dispatch<4>(C, B * parts, lds, s, x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
+  else first_conv_dispatch<1>(C, B * parts, lds, s, x, wf, scale, shift, tb, tb_stride, tb_div, out, B, n_pass, H, W, cout_p, parts);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

@@ -58,7 +58,7 @@ const char *kClassName[KC_COUNT] = {
     "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
     "conv_gemm_bf16x6_kernel<64,64>",
     "conv_strip_bf16x6_kernel<128,128>", "conv_strip_bf16x6_kernel<128,64>", "conv_strip_bf16x6_kernel<64,128>",
-    "conv_strip_bf16x6_kernel<64,64>", "splitk_epilogue_kernel", "first_conv_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "conv_strip_bf16x6_kernel<64,64>", "conv_strip_bf16x6_kernel<256,64>", "splitk_epilogue_kernel", "first_conv_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
@@ -238,6 +238,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   if (c.prec == 2) c.prec = 1;
   if (c.prec >= 3 && (p.tap_hi - p.tap_lo != 9 || !strip_admissible(p.W, 64, 64, 1))) c.prec = 1;   // full 3x3 walks of rows <= 63 px only
   if (c.prec == 4 && (p.cin_p >> 4) % 2) c.prec = 3;                // two chunks per step need an even chunk count
+  if (c.bm == 256 && c.prec < 3) c.bm = 128;                        // the 256-row tile exists in the strip kernels only
   if (p.x3 || j == 0 || p.M > kSplitMaxRows) c.splits = 1;          // (enc1: no slab; its conv2 keeps the fused x3 epilogue)
   if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * (c.prec == 4 ? 2 : 1)) != 0)
                   : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
@@ -583,9 +584,10 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
         if (prec >= 3 && !strip_ok) continue;
         if (prec == 4 && (p.cin_p >> 4) % 2) continue;
         if (prec == 1 && strip_ok) continue;                                  // the plain kernel competes where the strip one cannot run
-      for (int bm = 64; bm <= 128; bm += 64)
+      for (int bm = 64; bm <= 256; bm *= 2)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
+          if (bm == 256 && (prec < 3 || bn != 64)) continue;          // the 4 x 1 wave layout: strip kernels, 64-column tiles
           // dec1.conv2 with one N tile also evaluates the head (saves the head launch and dec1's output round trip)
           if (j == kBlocks - 1 && slot == 2 && h->head_fusion && h->desc.channels <= 3 && p.n_p <= 128 && bn != p.n_p) continue;
           // 3x3 walks split by taps 1/3/9; the strip kernel and single-tap layers by channel chunks 1/2/4/8
@@ -720,7 +722,7 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
   if (!h) return DT_E_NULL;
   if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H < 16 || W < 16 || H % 16 || W % 16 || batch_total < 1)
     return DT_E_ARG;
-  if ((bm != 64 && bm != 128) || (bn != 64 && bn != 128)) return DT_E_ARG;
+  if ((bm != 64 && bm != 128 && !(bm == 256 && bn == 64 && prec >= 3)) || (bn != 64 && bn != 128)) return DT_E_ARG;
   if (splits < 1 || splits > 9 || prec < 0 || prec > 4 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
   if (splits == 5 || splits == 6 || splits == 7) return DT_E_ARG;
   if (prec == 2) return DT_E_ARG;

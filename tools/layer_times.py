@@ -17,7 +17,7 @@ ws = h.workspace(512, 16, 16)
 lib = _hip.load()
 LAYERS = ((0, 2, "enc1.conv2", 1), (1, 1, "enc2.conv1", 1), (1, 2, "enc2.conv2", 1), (2, 1, "enc3.conv1", 2), (6, 1, "dec2.conv1", 4), (6, 2, "dec2.conv2", 2), (7, 1, "dec1.conv1", 2), (7, 2, "dec1.conv2", 2))
 for rnd in range(2):
-    for prec, bm, bn in ((3, 128, 128), (4, 128, 128), (4, 128, 64), (4, 64, 64)):
+    for prec, bm, bn in ((3, 128, 128), (4, 128, 128), (4, 128, 64), (4, 64, 64), (3, 256, 64), (4, 256, 64)):
         row = f"prec {prec} {bm:3d}x{bn:<3d}"
         for j, slot, name, sp in LAYERS:
             ms, fl = ctypes.c_float(), ctypes.c_double()
