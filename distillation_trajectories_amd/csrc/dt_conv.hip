@@ -152,19 +152,19 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
     bm = c.bm; bn = c.bn;
   }
   if ((bm != 64 && bm != 128 && !(bm == 256 && bn == 64 && p.prec >= 3)) || (bn != 64 && bn != 128) || p.n_p % bn || p.prec == 2 ||
-      p.prec < 0 || p.prec > 4)
+      p.prec < 0 || p.prec > 5)
     return DT_E_ARG;
   const bool tall_m = bm == 128, wide_n = bn == 128;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   if (p.splits < 1 || (p.splits > 1 && !p.slab)) return DT_E_ARG;
-  if (p.prec >= 3 ? ((p.cin_p >> 4) % (p.splits * (p.prec == 4 ? 2 : 1)) != 0) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % p.splits != 0)) return DT_E_ARG;
+  if (p.prec >= 3 ? ((p.cin_p >> 4) % (p.splits * strip_kc(p.prec, bm, bn)) != 0) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % p.splits != 0)) return DT_E_ARG;
   // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
   if (p.in2 && (p.splits != 1 || !p.w2 || !p.bias2 || p.cin2_p % 16)) return DT_E_ARG;
   const double flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));
   if (p.prec >= 3) {
-    ProfileScope prof(bm == 256 ? KC_CONVS_256x64 : tall_m ? (wide_n ? KC_CONVS_128x128 : KC_CONVS_128x64) : (wide_n ? KC_CONVS_64x128 : KC_CONVS_64x64),
+    ProfileScope prof(p.prec == 5 ? (tall_m ? KC_CONVS_K128x64 : (wide_n ? KC_CONVS_K64x128 : KC_CONVS_K64x64)) : bm == 256 ? KC_CONVS_256x64 : tall_m ? (wide_n ? KC_CONVS_128x128 : KC_CONVS_128x64) : (wide_n ? KC_CONVS_64x128 : KC_CONVS_64x64),
                       flops, 4.0 * p.M * ((double)p.cin_real + p.cout_real), s);
-    const int st = launch_conv_strip(p, bm, bn, p.prec == 4 ? 2 : 1, s);
+    const int st = launch_conv_strip(p, bm, bn, p.prec, s);
     if (st) return st;
   } else if (p.prec == 1) {
     ProfileScope prof(tall_m ? (wide_n ? KC_CONVB_128x128 : KC_CONVB_128x64) : (wide_n ? KC_CONVB_64x128 : KC_CONVB_64x64),

@@ -54,10 +54,14 @@ constexpr int epilogue_stage_floats() { return WM * 32 * (BN + 4); }
 // counter per tile, the last workgroup to arrive sums the slabs behind an agent-scope acquire -- was built and measured
 // in round 2: bit-identical results, the same time at batch 256 (the acquire + the serial slab reads of one workgroup
 // per tile cost what the second launch costs) and 38 % slower at batch 8, where tiles are few and splits deep.)
-template <int MI, int NI, int WM = 2>
+//
+// WK > 1 (strip kernel with the K split across waves): WK waves hold partial sums of the same tile; each writes its own
+// copy of the stage and a unit is the sum of the copies in wave order (deterministic).
+template <int MI, int NI, int WM = 2, int WK = 1>
 __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI], float *stage, int m0, int n0, int wm, int wn,
-                                     int half, int l31) {
-  constexpr int BN = NI * 32 * (4 / WM), P = BN + 4, C4 = BN / 4, U = WM * C4 / 8;   // U float4 units per thread and pass
+                                     int half, int l31, int wk = 0) {
+  constexpr int BN = NI * 32 * (4 / (WM * WK)), P = BN + 4, C4 = BN / 4, U = WM * C4 / 8;   // U float4 units per thread and pass
+  constexpr int COPY = WM * 32 * P;
   const int tid = threadIdx.x;
   const int HW = p.H * p.W;
   const bool slab_mode = p.splits > 1;
@@ -67,6 +71,13 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
   const int n = n0 + c4 * 4;
   const bool n_ok = n < p.cout_p;
   const int nn = n_ok ? n : 0;
+  auto unit = [&](int k) __attribute__((always_inline)) {
+    const float *src = stage + (row0 + k * (256 / C4)) * P + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+#pragma unroll
+    for (int c = 1; c < WK; ++c) v += *reinterpret_cast<const f32x4 *>(src + c * COPY);
+    return v;
+  };
   auto unit_row = [&](int mi, int k) { const int row = row0 + k * (256 / C4); return m0 + (row >> 5) * (MI * 32) + mi * 32 + (row & 31); };
   auto to_stage = [&](int mi) __attribute__((always_inline)) {
     __syncthreads();                                   // the main loop (or the previous pass) is done with this LDS
@@ -75,7 +86,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int L = 4 * half + (r & 3) + 8 * (r >> 2);
-        stage[(wm * 32 + L) * P + wn * (NI * 32) + ni * 32 + l31] = acc[mi][ni][r];
+        stage[wk * COPY + (wm * 32 + L) * P + wn * (NI * 32) + ni * 32 + l31] = acc[mi][ni][r];
       }
     __syncthreads();
   };
@@ -89,7 +100,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       for (int k = 0; k < U; ++k) {
         const int m = unit_row(mi, k);
         if (n_ok && m < p.M)
-          *reinterpret_cast<f32x4 *>(slab + (size_t)m * p.cout_p + n) = *reinterpret_cast<const f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4);
+          *reinterpret_cast<f32x4 *>(slab + (size_t)m * p.cout_p + n) = unit(k);
       }
     }
     return;                                            // splitk_epilogue_kernel finishes the layer
@@ -107,7 +118,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       ok[k] = n_ok && mrow[k] < p.M;
     }
 #pragma unroll
-    for (int k = 0; k < U; ++k) v[k] = *reinterpret_cast<const f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4);
+    for (int k = 0; k < U; ++k) v[k] = unit(k);
     if (p.in2) {
       const f32x4 b2 = *reinterpret_cast<const f32x4 *>(p.bias2 + nn);   // BN/ReLU were applied before the skip walk
 #pragma unroll

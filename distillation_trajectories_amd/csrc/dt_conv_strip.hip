@@ -38,14 +38,21 @@ __host__ __device__ inline int strip_halo(int W, int bm) { return bm % W == 0 ? 
 // 4 no fragment reads after the first step, 5 no strip re-staging
 // KC = 16-channel chunks staged and multiplied per step (1 or 2): KC = 2 halves the barriers and doubles the
 // MFMAs between them at twice the LDS footprint and staging registers (2 waves/SIMD instead of 3).
-template <int BM, int BN, int ABL = 0, int KC = 1>
+// WK = waves that share one output tile and split the step's KC chunks between them (1, 2 or 4): small layers need
+// small workgroup tiles to fill the chip, and a 64 x 64 tile cut 2 x 2 leaves each wave 32 x 32 (6 fragment reads per
+// 6 MFMAs, ~100 TF/s).  With WK = 4 every wave keeps a 64 x 64 accumulator (12 reads per 24 MFMAs) over a quarter of
+// the channels and the four partial tiles are summed in wave order in the staged epilogue -- split-K without slabs.
+template <int BM, int BN, int ABL = 0, int KC = 1, int WK = 1>
 __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel(const ConvParams p) {
   // four waves: 2 x 2 over the tile, or 4 x 1 for the 256 x 64 tile (a 64 x 64 wave tile -- 12 fragment reads per 24
-  // MFMAs, like the 128 x 128 tile -- for layers with 64 output channels, where 128 x 64 leaves each wave 64 x 32)
-  constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, NT = 256;
+  // MFMAs, like the 128 x 128 tile -- for layers with 64 output channels, where 128 x 64 leaves each wave 64 x 32),
+  // or WM x 1 x WK with the K split
+  constexpr int WN = WK > 1 ? BN / 64 : (BM == 256 ? 1 : 2), WM = 4 / (WN * WK), NT = 256;
   constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
+  constexpr int KW = KC / WK;                                      // chunks of a step one wave multiplies
+  static_assert(KC % WK == 0 && MI * 32 * WM == BM && NI * 32 * WN == BN && (WK == 1 || (MI == 2 && NI == 2)), "wave layout");
   constexpr int PLANE_B = BN * 16, STAGE_B = 3 * PLANE_B;         // bf16 elements
-  constexpr int AP = BM == 256 ? 3 : 2;                            // strip items (row, k-half) per thread
+  constexpr int AP = BM == 256 ? 3 : (KC == 4 ? 1 : 2);            // strip items (row, k-half) per thread (K = 64 steps: rows of at most 31 px)
   const int halo = strip_halo(p.W, BM);
   const int R = BM + 2 * halo;                                     // strip rows
   const int RZ = (R + 7) & ~7;                                     // 8 all-zero rows start here (multiple of 8)
@@ -53,8 +60,9 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   __bf16 *As = strip_lds;                                          // [KC][3][RZ+8][16]
   __bf16 *Bs = strip_lds + KC * 3 * PLANE_A;                       // [2][KC][3][BN][16]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: chunk and tile offsets stay in scalar registers
+  const int wk = wave % WK, wm = (wave / WK) / WN, wn = (wave / WK) % WN;
   const int half = lane >> 5, l31 = lane & 31;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int HW = p.H * p.W;
@@ -78,10 +86,16 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     s_lds[i] = srow * 16 + ((hh ^ ((srow >> 3) & 1)) << 3);
   }
   // ---- weight staging: the three plane tiles of one (tap, chunk) are contiguous [BN][16] bf16 runs
-  const bool b_thread = tid < BN * 2;
-  const __bf16 *wbase = reinterpret_cast<const __bf16 *>(p.w) + (size_t)n0 * 16 + tid * 8;
-  const __bf16 *wbase2 = reinterpret_cast<const __bf16 *>(p.w2) + (size_t)n0 * 16 + tid * 8;
+  // (with the K split and BN = 64 both thread halves stage: even / odd (chunk, plane) tiles)
+  constexpr bool B_ALL = WK > 1 && BN * 4 == NT;
+  constexpr int NB = B_ALL ? KC * 3 / 2 : KC * 3, SB = B_ALL ? 2 : 1;
+  static_assert(!B_ALL || (KC * 3) % 2 == 0, "weight staging");
+  const bool b_thread = B_ALL || tid < BN * 2;
+  const int bt = B_ALL ? (tid & (BN * 2 - 1)) : tid, bsub = B_ALL ? tid / (BN * 2) : 0;
   const size_t w_plane = (size_t)p.n_p * 16;
+  const __bf16 *wbase = reinterpret_cast<const __bf16 *>(p.w) + (size_t)n0 * 16 + bt * 8 + bsub * w_plane;
+  const __bf16 *wbase2 = reinterpret_cast<const __bf16 *>(p.w2) + (size_t)n0 * 16 + bt * 8 + bsub * w_plane;
+  const int b_lds = bsub * PLANE_B + bt * 8;
 
   // ---- fragment rows: strip row of the centre tap and the 9-bit tap-validity mask
   int a_row[MI];
@@ -123,7 +137,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   const int n_chunks = n_main + (p.in2 ? (p.cin2_p >> 4) / KC : 0);
 
   f32x4 sa0[KC][AP], sa1[KC][AP];
-  u32x4 rb[KC][3];
+  u32x4 rb[NB];
   auto load_strip = [&](int ch) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk)
@@ -172,18 +186,15 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     if (b_thread) {
       const __bf16 *wt = ABL == 6 ? wbase : wrun;                  // ABL 6: every tile re-reads the first one (cache-hot)
 #pragma unroll
-      for (int kk = 0; kk < KC; ++kk)                              // consecutive chunks of one tap are 3 planes apart
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rb[kk][pl] = *reinterpret_cast<const u32x4 *>(wt + (kk * 3 + pl) * w_plane);
+      for (int i = 0; i < NB; ++i)                                 // tile i = (chunk, plane): consecutive chunks of one tap are 3 planes apart
+        rb[i] = *reinterpret_cast<const u32x4 *>(wt + (SB * i) * w_plane);
     }
   };
   auto write_b = [&](int stage) __attribute__((always_inline)) {
     if (b_thread) {
       __bf16 *B = Bs + stage * KC * STAGE_B;
 #pragma unroll
-      for (int kk = 0; kk < KC; ++kk)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4 *>(B + (kk * 3 + pl) * PLANE_B + tid * 8) = rb[kk][pl];
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4 *>(B + (SB * i) * PLANE_B + b_lds) = rb[i];
     }
   };
 
@@ -215,10 +226,11 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   // left as scalar control.
   const long long tl_pro = p.ablate == 8 ? wall_clock64() : 0;
   int step = 0;
+  bool stage_next_strip = true;            // false: the next step is a skip step that takes its activations straight from global memory
   auto do_step = [&](auto TT, int ch, bool first_tap, bool last_tap, bool next_chunk, int adv) __attribute__((always_inline)) {
     constexpr int tt = decltype(TT)::value;
     const bool more = !last_tap || next_chunk;
-    if (first_tap && next_chunk && ABL != 5) load_strip(ch + 1);   // lands while this chunk's taps run
+    if (first_tap && next_chunk && stage_next_strip && ABL != 5) load_strip(ch + 1);   // lands while this chunk's taps run
     if (more && ABL != 2) load_b(adv);
     {
       int wv = p.W;
@@ -237,7 +249,8 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
         a_e[mi] = lrow * 16 + ((half ^ ((srow >> 3) & 1)) << 3);
       }
 #pragma unroll
-      for (int kk = 0; kk < KC; ++kk) {
+      for (int kw = 0; kw < KW; ++kw) {
+        const int kk = wk * KW + kw;                                // this wave's chunk of the step (all of them without the K split)
         const __bf16 *A = As + kk * 3 * PLANE_A;
         const __bf16 *B = Bs + ((step & 1) * KC + kk) * STAGE_B;
         bf16x8 fb[NI][3];
@@ -276,12 +289,72 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     if (ABL == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(1); }
     if (more && ABL != 2) write_b((step + 1) & 1);
     stamp(2);
-    if (last_tap && next_chunk && ABL != 5) {
+    if (last_tap && next_chunk && stage_next_strip && ABL != 5) {
       __syncthreads();                                             // every wave is done with this chunk's strip
       write_strip();
     }
     if (ABL != 1 || last_tap) __syncthreads();
     stamp(3);
+    ++step;
+  };
+
+  // ---- fused 1x1 skip walk with the activations taken straight from global memory (wave tiles of at most 2 x 32 rows x
+  // chunks per step): a lane's A fragment of a 32 x 32 x 16 MFMA is 8 consecutive channels of ONE pixel, so two float4 loads
+  // and the three-way split give it without LDS.  The strip path restaged the tile per step behind two barriers with the loads
+  // of step s + 1 issued only one (single-tap) step ahead: 25-40 us per layer for 2-4 GFLOP.  Here the loads of step s + 2 are
+  // issued when step s has consumed its registers (two register sets, the strip staging registers being idle), the weight
+  // tile keeps its double buffer and a step has one barrier.
+  constexpr bool DIRECT = MI * KW <= 2 && KC >= 2 && ABL == 0;   // (K = 16 steps: 3 waves per SIMD leave no registers for the two sets)
+  f32x4 ga0[KW][MI][2], ga1[KW][MI][2];
+  const int n_skip = p.in2 ? (p.cin2_p >> 4) / KC : 0;
+  auto load_a = [&](f32x4 (&g)[KW][MI][2], int s2) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int c2 = s2 * KC + wk * KW + kw;
+        const int m = m0 + wm * (MI * 32) + mi * 32 + l31;
+        g[kw][mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; g[kw][mi][1] = g[kw][mi][0];
+        if (m < p.M) {
+          const float *src = (p.in2_b && c2 >= p.cc_a) ? p.in2_b + (size_t)m * p.b_stride + (c2 - p.cc_a) * 16 + half * 8
+                                                       : p.in2 + (size_t)m * p.cin2_p + c2 * 16 + half * 8;
+          g[kw][mi][0] = *reinterpret_cast<const f32x4 *>(src);
+          g[kw][mi][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
+      }
+  };
+  auto skip_step = [&](f32x4 (&g)[KW][MI][2], int s2) __attribute__((always_inline)) {
+    const bool more = s2 + 1 < n_skip;
+    if (more) load_b(ADV_SKIP);
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw) {
+      const int kk = wk * KW + kw;
+      const __bf16 *B = Bs + ((step & 1) * KC + kk) * STAGE_B;
+      bf16x8 fb[NI][3];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) fb[ni][pl] = *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        bf16x8 fa[3];
+        split8(g[kw][mi][0], g[kw][mi][1], fa[0], fa[1], fa[2]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          f32x16 c = acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ni][0], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+      }
+    }
+    if (s2 + 2 < n_skip) load_a(g, s2 + 2);
+    if (more) write_b((step + 1) & 1);
+    __syncthreads();
     ++step;
   };
 
@@ -298,7 +371,13 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
       if ((ch ^ prio_grp) & 1) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
-    const bool next_chunk = ch + 1 < n_chunks;
+    // (with the K split the fused skip walk starts from a fresh prologue after the mid-kernel reduction below)
+    const bool next_chunk = ch + 1 < ((WK > 1 && p.in2) ? n_main : n_chunks);
+    if (DIRECT && WK == 1 && p.in2 && ch + 1 == n_main) {          // the skip walk's first two steps load during this chunk's taps
+      stage_next_strip = false;
+      load_a(ga0, 0);
+      if (n_skip > 1) load_a(ga1, 1);
+    }
     do_step(std::integral_constant<int, 0>{}, ch, true, false, next_chunk, ADV_TAP);
     do_step(std::integral_constant<int, 1>{}, ch, false, false, next_chunk, ADV_TAP);
     do_step(std::integral_constant<int, 2>{}, ch, false, false, next_chunk, ADV_TAP);
@@ -308,13 +387,62 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     do_step(std::integral_constant<int, 6>{}, ch, false, false, next_chunk, ADV_TAP);
     do_step(std::integral_constant<int, 7>{}, ch, false, false, next_chunk, ADV_TAP);
     do_step(std::integral_constant<int, 8>{}, ch, false, true, next_chunk, ch + 1 < n_main ? ADV_GROUP : ADV_SKIP0);
-    if (ch + 1 == n_main && p.in2) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
+    if (ch + 1 == n_main && p.in2) {
+      if constexpr (WK == 1) {
+        conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
+      } else {
+        // BN + ReLU apply to the COMPLETE 3x3 sum: the WK partial tiles meet in LDS (free after the last step's barrier), wave
+        // 0 of each group continues with relu(bn(sum)) and the others with zero, and the skip walk restarts the pipeline
+        constexpr int P = BN + 4, COPY = WM * 32 * P;
+        float *red = reinterpret_cast<float *>(strip_lds);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          if (mi) __syncthreads();
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              red[wk * COPY + (wm * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) * P + wn * (NI * 32) + ni * 32 + l31] = acc[mi][ni][r];
+          __syncthreads();
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float *src = red + (wm * 32 + 4 * half + (r & 3) + 8 * (r >> 2)) * P + wn * (NI * 32) + ni * 32 + l31;
+              float v = src[0];
+#pragma unroll
+              for (int c = 1; c < WK; ++c) v += src[c * COPY];
+              acc[mi][ni][r] = wk == 0 ? v : 0.f;
+            }
+        }
+        if (wk == 0) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
+        __syncthreads();
+        load_b(ADV_SKIP0);
+        if (DIRECT) {
+          load_a(ga0, 0);
+          if (n_skip > 1) load_a(ga1, 1);
+        } else {
+          load_strip(n_main);
+          if (tid < 48 * KC) *reinterpret_cast<u32x4 *>(As + (tid >> 4) * PLANE_A + RZ * 16 + (tid & 15) * 8) = u32x4{0u, 0u, 0u, 0u};
+          write_strip();
+        }
+        write_b(step & 1);
+        __syncthreads();
+      }
+    }
   }
   __builtin_amdgcn_s_setprio(0);
-  for (int ch = n_main; ch < n_chunks; ++ch)                       // fused 1x1 skip walk: centre tap only
-    do_step(std::integral_constant<int, 4>{}, ch, true, true, ch + 1 < n_chunks, ADV_SKIP);
+  if (DIRECT) {                                                    // fused 1x1 skip walk, activations from global memory
+    for (int s2 = 0; s2 < n_skip; s2 += 2) {
+      skip_step(ga0, s2);
+      if (s2 + 1 < n_skip) skip_step(ga1, s2 + 1);
+    }
+  } else {
+    for (int ch = n_main; ch < n_chunks; ++ch)                     // fused 1x1 skip walk through the strip: centre tap only
+      do_step(std::integral_constant<int, 4>{}, ch, true, true, ch + 1 < n_chunks, ADV_SKIP);
+  }
   const long long tl1 = p.ablate == 8 ? wall_clock64() : 0;
-  conv_epilogue<MI, NI, WM>(p, acc, reinterpret_cast<float *>(strip_lds), m0, n0, wm, wn, half, l31);
+  conv_epilogue<MI, NI, WM, WK>(p, acc, reinterpret_cast<float *>(strip_lds), m0, n0, wm, wn, half, l31, wk);
   if (ABL == 9) {                          // per-wave phase sums (cycles) + step count into the unused split-K slab
     if (lane == 0) {
       unsigned long long *rec = reinterpret_cast<unsigned long long *>(p.slab) + 8 * (4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + wave);
@@ -330,21 +458,31 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   }
 }
 
+// chunks per step of a strip arithmetic code: 3 -> 1, 4 -> 2, 5 (K split across the waves) -> 4 waves x 1 chunk on the
+// 64 x 64 tile, 2 waves x 1 chunk on the 128 x 64 and 64 x 128 tiles
+int strip_kc(int prec, int bm, int bn) { return prec == 5 ? (bm == 64 && bn == 64 ? 4 : 2) : (prec == 4 ? 2 : 1); }
+
 static size_t strip_lds_bytes(int W, int bm, int bn, int kc) {
   const int R = bm + 2 * strip_halo(W, bm);
   const size_t loop = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 8) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
-  const size_t stage = (size_t)(bm == 256 ? 128 : 64) * (bn + 4) * sizeof(float);   // the staged epilogue reuses the same LDS
+  // the staged epilogue reuses the same LDS: WM * 32 rows per copy, one copy per K-split wave (128 rows in every layout)
+  const size_t stage = (size_t)(bm == 256 || kc == 4 || (kc == 2 && bm == 128 && bn == 64) ? 128 : 64) * (bn + 4) * sizeof(float);   // (64 x 128 K-split: 2 x 32 rows)
   return loop > stage ? loop : stage;
 }
 
-bool strip_admissible(int W, int bm, int bn, int kc) {
+bool strip_admissible(int W, int bm, int bn, int prec) {
   if (W + 1 > 64) return false;                                    // 2 (3) strip items per thread cover BM + 2(W+1) <= 256 (384) rows
-  if (bm == 256 && bn != 64) return false;                         // the 4 x 1 wave layout exists for 64-column tiles only
-  return strip_lds_bytes(W, bm, bn, kc) <= (kc == 2 ? 98304u : 65536u);
+  if (bm == 256 && (bn != 64 || prec == 5)) return false;          // the 4 x 1 wave layout exists for 64-column tiles only
+  if (prec == 5 && (bm > 128 || (bm == 128 && bn == 128))) return false;
+  if (strip_kc(prec, bm, bn) == 4 && W + 1 > 32) return false;     // one strip item per thread: BM + 2(W+1) <= 128 rows
+  return strip_lds_bytes(W, bm, bn, strip_kc(prec, bm, bn)) <= (prec == 3 ? 65536u : 98304u);
 }
 
-int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s) {
-  if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || (kc != 1 && kc != 2)) return DT_E_ARG;
+int launch_conv_strip(const ConvParams &p, int bm, int bn, int prec, hipStream_t s) {
+  const int kc = strip_kc(prec, bm, bn);
+  if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || prec < 3 || prec > 5) return DT_E_ARG;
+  if (prec == 5 && (bm > 128 || (bm == 128 && bn == 128))) return DT_E_ARG;
+  if (kc == 4 && p.W + 1 > 32) return DT_E_SHAPE;
   if ((p.cin_p >> 4) % (p.splits * kc) || (p.in2 && (p.cin2_p >> 4) % kc)) return DT_E_ARG;
   if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 (3) strip items per thread cover BM + 2(W+1) <= 256 (384) rows
   if (bm == 256 && bn != 64) return DT_E_ARG;
@@ -364,11 +502,14 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
     DT_LAUNCH_CHECK();
     return DT_OK;
   }
-  if (kc == 2) {
+  if (prec >= 4) {
     static std::once_flag attr_once;   // 128x128 needs 80 KB of dynamic LDS; launches come from several host threads
     static int attr_status = DT_OK;
     std::call_once(attr_once, [] {
-      const void *fns[5] = {reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<256, 64, 0, 2>),
+      const void *fns[8] = {reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 128, 0, 2, 2>),
+                            reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 64, 0, 4, 4>),
+                            reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 64, 0, 2, 2>),
+                            reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<256, 64, 0, 2>),
                             reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 128, 0, 2>),
                             reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<128, 64, 0, 2>),
                             reinterpret_cast<const void *>(&conv_strip_bf16x6_kernel<64, 128, 0, 2>),
@@ -380,7 +521,10 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s
     });
     if (attr_status != DT_OK) return attr_status;
     if (lds > 98304) return DT_E_SHAPE;
-    if (bm == 256) conv_strip_bf16x6_kernel<256, 64, 0, 2><<<grid, 256, lds, s>>>(p);
+    if (prec == 5 && bn == 128) conv_strip_bf16x6_kernel<64, 128, 0, 2, 2><<<grid, 256, lds, s>>>(p);
+    else if (prec == 5 && bm == 64) conv_strip_bf16x6_kernel<64, 64, 0, 4, 4><<<grid, 256, lds, s>>>(p);
+    else if (prec == 5) conv_strip_bf16x6_kernel<128, 64, 0, 2, 2><<<grid, 256, lds, s>>>(p);
+    else if (bm == 256) conv_strip_bf16x6_kernel<256, 64, 0, 2><<<grid, 256, lds, s>>>(p);
     else if (bm == 128 && bn == 128) conv_strip_bf16x6_kernel<128, 128, 0, 2><<<grid, 256, lds, s>>>(p);
     else if (bm == 128) conv_strip_bf16x6_kernel<128, 64, 0, 2><<<grid, 256, lds, s>>>(p);
     else if (bn == 128) conv_strip_bf16x6_kernel<64, 128, 0, 2><<<grid, 256, lds, s>>>(p);

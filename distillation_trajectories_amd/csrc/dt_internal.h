@@ -24,7 +24,7 @@ namespace dt {
 enum KernelClass {
   KC_CONV_128x128 = 0, KC_CONV_128x64, KC_CONV_64x128, KC_CONV_64x64,
   KC_CONVB_128x128, KC_CONVB_128x64, KC_CONVB_64x128, KC_CONVB_64x64,
-  KC_CONVS_128x128, KC_CONVS_128x64, KC_CONVS_64x128, KC_CONVS_64x64, KC_CONVS_256x64,
+  KC_CONVS_128x128, KC_CONVS_128x64, KC_CONVS_64x128, KC_CONVS_64x64, KC_CONVS_256x64, KC_CONVS_K128x64, KC_CONVS_K64x64, KC_CONVS_K64x128,
   KC_SPLITK_EPILOGUE, KC_FIRST_CONV, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
   KC_WASSERSTEIN, KC_RESAMPLE,
   KC_COUNT
@@ -117,9 +117,10 @@ struct ConvParams {
 
 int launch_conv(const ConvParams &p, hipStream_t s);
 int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s);
-int launch_conv_strip(const ConvParams &p, int bm, int bn, int kc, hipStream_t s);   // prec 3 (kc 1) / 4 (kc 2): 3x3 only
+int launch_conv_strip(const ConvParams &p, int bm, int bn, int prec, hipStream_t s);   // prec 3 / 4 / 5: 3x3 only
+int strip_kc(int prec, int bm, int bn);                         // 16-channel chunks per step of a strip arithmetic code
 // whether the strip kernel can run a bm x bn tile with kc chunks per step on rows of W pixels (staging reach, LDS)
-bool strip_admissible(int W, int bm, int bn, int kc);
+bool strip_admissible(int W, int bm, int bn, int prec);
 int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int n_p,
                             int split_c, int split_cp, hipStream_t s);
 struct ConvChoice { int bm, bn, splits, prec, fuse; };

@@ -58,7 +58,8 @@ const char *kClassName[KC_COUNT] = {
     "conv_gemm_bf16x6_kernel<128,128>", "conv_gemm_bf16x6_kernel<128,64>", "conv_gemm_bf16x6_kernel<64,128>",
     "conv_gemm_bf16x6_kernel<64,64>",
     "conv_strip_bf16x6_kernel<128,128>", "conv_strip_bf16x6_kernel<128,64>", "conv_strip_bf16x6_kernel<64,128>",
-    "conv_strip_bf16x6_kernel<64,64>", "conv_strip_bf16x6_kernel<256,64>", "splitk_epilogue_kernel", "first_conv_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
+    "conv_strip_bf16x6_kernel<64,64>", "conv_strip_bf16x6_kernel<256,64>", "conv_strip_bf16x6_kernel<128,64,K2>",
+    "conv_strip_bf16x6_kernel<64,64,K4>", "conv_strip_bf16x6_kernel<64,128,K2>", "splitk_epilogue_kernel", "first_conv_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
 }  // namespace
 
@@ -229,18 +230,20 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   ConvChoice c = choice ? *choice : heuristic_choice(p.M, p.n_p, taps);
   if (!choice) {   // untuned default per mode; the strip kernel wherever the full 3x3 walk runs (uniformly >= the plain one)
     c.prec = u->precision == DT_PREC_FP32 ? 0 : 1;
-    if (c.prec == 1 && p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && strip_admissible(p.W, 64, 64, 1)) {
+    if (c.prec == 1 && p.ksize == 3 && p.tap_hi - p.tap_lo == 9 && strip_admissible(p.W, 64, 64, 3)) {
       c.prec = 3;
       const int cc = p.cin_p >> 4;   // tap groups 3 / 9 become channel-chunk groups 4 / 8 where they divide
       c.splits = c.splits == 9 ? (cc % 8 == 0 ? 8 : (cc % 4 == 0 ? 4 : 1)) : (c.splits == 3 ? (cc % 4 == 0 ? 4 : (cc % 2 == 0 ? 2 : 1)) : 1);
     }
   }
   if (c.prec == 2) c.prec = 1;
-  if (c.prec >= 3 && (p.tap_hi - p.tap_lo != 9 || !strip_admissible(p.W, 64, 64, 1))) c.prec = 1;   // full 3x3 walks of rows <= 63 px only
+  if (c.prec >= 3 && (p.tap_hi - p.tap_lo != 9 || !strip_admissible(p.W, 64, 64, 3))) c.prec = 1;   // full 3x3 walks of rows <= 63 px only
+  if (c.prec == 5 && (c.bm > 128 || (c.bm == 128 && c.bn == 128))) c.prec = 4;   // K split across waves: tiles below 128 x 128
+  if (c.prec == 5 && (p.cin_p >> 4) % strip_kc(5, c.bm, c.bn)) c.prec = 4;
   if (c.prec == 4 && (p.cin_p >> 4) % 2) c.prec = 3;                // two chunks per step need an even chunk count
   if (c.bm == 256 && c.prec < 3) c.bm = 128;                        // the 256-row tile exists in the strip kernels only
   if (p.x3 || j == 0 || p.M > kSplitMaxRows) c.splits = 1;          // (enc1: no slab; its conv2 keeps the fused x3 epilogue)
-  if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * (c.prec == 4 ? 2 : 1)) != 0)
+  if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * strip_kc(c.prec, c.bm, c.bn)) != 0)
                   : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
   // encoder blocks enc1..enc4 feed a 2x2 max pool: folded into this launch's staged epilogue where a 32-row tile holds
@@ -253,7 +256,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     p.head_w = u->final_w; p.head_b = u->final_b; p.head_out = ws + pl.lowres;
     p.head_c = u->desc.channels; p.head_cin = u->desc.dims[0];
   }
-  if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0 && !(c.prec == 4 && (k.cin_p >> 4) % 2)) {
+  if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0 && !(c.prec >= 4 && (k.cin_p >> 4) % strip_kc(c.prec, c.bm, c.bn))) {
     // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
     p.add = nullptr;
     p.in2 = in; p.w2 = c.prec >= 1 ? k.wrb : k.wr; p.bias2 = k.hr; p.cin2_p = k.cin_p; p.cin2_real = k.cin;
@@ -270,7 +273,7 @@ bool concat_in_place(const dt_unet *u, int j, float *ws, const Plan &pl, int Bt,
   ConvParams c1, c2;
   if (!conv_slot(u, j, 1, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][1] : nullptr, c1)) return false;
   if (!conv_slot(u, j, 2, ws, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][2] : nullptr, c2)) return false;
-  return c1.prec >= 3 && c1.prec <= 4 && c2.prec >= 3 && c2.prec <= 4 && c2.in2 != nullptr;
+  return c1.prec >= 3 && c1.prec <= 5 && c2.prec >= 3 && c2.prec <= 5 && c2.in2 != nullptr;
 }
 
 int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
@@ -575,28 +578,29 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
       // Kernel families worth timing (the search is paid once per model and shape, so it is pruned to what the
       // per-layer tables show can win): exact-fp32 mode -> the fp32-MFMA kernel only; otherwise the strip kernels
       // for full 3x3 walks and the plain split-bf16 kernel for everything else.
-      for (int prec = 0; prec <= 4 && st == DT_OK; ++prec) {
+      for (int prec = 0; prec <= 5 && st == DT_OK; ++prec) {
         if (h->precision == DT_PREC_FP32 ? prec != 0 : prec == 0) continue;
         if (prec == 2) continue;
         static const int skip_mask = getenv("DT_TUNE_SKIP_PREC") ? atoi(getenv("DT_TUNE_SKIP_PREC")) : 0;   // experiments: bit p drops family p
         if (skip_mask & (1 << prec)) continue;
-        const bool strip_ok = full3x3 && strip_admissible(p.W, 64, 64, 1);   // some strip tile fits this row width
+        const bool strip_ok = full3x3 && strip_admissible(p.W, 64, 64, 3);   // some strip tile fits this row width
         if (prec >= 3 && !strip_ok) continue;
-        if (prec == 4 && (p.cin_p >> 4) % 2) continue;
+        if (prec >= 4 && (p.cin_p >> 4) % 2) continue;
         if (prec == 1 && strip_ok) continue;                                  // the plain kernel competes where the strip one cannot run
       for (int bm = 64; bm <= 256; bm *= 2)
         for (int bn = 64; bn <= 128; bn += 64) {
           if (p.n_p % bn) continue;
           if (bm == 256 && (prec < 3 || bn != 64)) continue;          // the 4 x 1 wave layout: strip kernels, 64-column tiles
+          if (prec == 5 && (bm > 128 || (bm == 128 && bn == 128))) continue;   // K split across the waves: tiles below 128 x 128
           // dec1.conv2 with one N tile also evaluates the head (saves the head launch and dec1's output round trip)
           if (j == kBlocks - 1 && slot == 2 && h->head_fusion && h->desc.channels <= 3 && p.n_p <= 128 && bn != p.n_p) continue;
           // 3x3 walks split by taps 1/3/9; the strip kernel and single-tap layers by channel chunks 1/2/4/8
           const long long tiles = (long long)((p.M + bm - 1) / bm) * (p.n_p / bn);
           for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= ((prec >= 3 || !walk9) ? 2 : 3))
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
-            if ((prec >= 3 || !walk9) && (p.cin_p >> 4) % (sp * (prec == 4 ? 2 : 1))) continue;
-            if (prec == 4 && fuse && (kw.cin_p >> 4) % 2) continue;
-            if (prec >= 3 && !strip_admissible(p.W, bm, bn, prec == 4 ? 2 : 1)) continue;   // LDS footprint of this tile
+            if ((prec >= 3 || !walk9) && (p.cin_p >> 4) % (sp * (prec >= 3 ? strip_kc(prec, bm, bn) : 1))) continue;
+            if (prec >= 4 && fuse && (kw.cin_p >> 4) % strip_kc(prec, bm, bn)) continue;
+            if (prec >= 3 && !strip_admissible(p.W, bm, bn, prec)) continue;   // LDS footprint of this tile
             if (sp > 1 && tiles * (sp / 2) >= 1024) continue;          // already >= 4 workgroups per CU without this split
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
@@ -723,7 +727,8 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
   if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H < 16 || W < 16 || H % 16 || W % 16 || batch_total < 1)
     return DT_E_ARG;
   if ((bm != 64 && bm != 128 && !(bm == 256 && bn == 64 && prec >= 3)) || (bn != 64 && bn != 128)) return DT_E_ARG;
-  if (splits < 1 || splits > 9 || prec < 0 || prec > 4 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
+  if (splits < 1 || splits > 9 || prec < 0 || prec > 5 || (fuse && (slot != 2 || splits != 1))) return DT_E_ARG;
+  if (prec == 5 && (bm > 128 || (bm == 128 && bn == 128))) return DT_E_ARG;
   if (splits == 5 || splits == 6 || splits == 7) return DT_E_ARG;
   if (prec == 2) return DT_E_ARG;
   if (h->blk[block].n_p % bn) return DT_E_ARG;

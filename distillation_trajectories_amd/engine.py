@@ -205,7 +205,7 @@ class UNetHandle:
                                                    ctypes.byref(sp), ctypes.byref(pr), ctypes.byref(tu)), "dt_unet_conv_choice")
                 if bm.value:
                     out.append((BLOCK_NAMES[j], ("skip", "conv1", "conv2")[slot], bm.value, bn.value, sp.value,
-                                ("fp32", "split-bf16", "-", "split-bf16-strip", "split-bf16-strip32", "-", "-", "-")[pr.value & 7]
+                                ("fp32", "split-bf16", "-", "split-bf16-strip", "split-bf16-strip32", "split-bf16-stripk", "-", "-")[pr.value & 7]
                                 + ("+skip" if pr.value & 8 else ""), bool(tu.value)))
         return out
 

@@ -1,4 +1,4 @@
-"""Quick A/B table: the big strip-kernel layers under explicit (tile, split, arithmetic) choices, 20 back-to-back launches each."""
+"""conv2 + folded 1x1 skip walk (one launch) under explicit (arithmetic, tile) choices, 20 back-to-back launches each."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,15 +15,13 @@ tb = h.time_bias([10, 10], [_hip.COND_NONE, _hip.COND_ONE])
 h.forward(x, tb, 2, 256, tune=False)
 ws = h.workspace(512, 16, 16)
 lib = _hip.load()
-LAYERS = ((0, 2, "enc1.conv2", 1), (1, 1, "enc2.conv1", 1), (1, 2, "enc2.conv2", 1), (2, 1, "enc3.conv1", 2), (6, 1, "dec2.conv1", 4), (6, 2, "dec2.conv2", 2), (7, 1, "dec1.conv1", 2), (7, 2, "dec1.conv2", 2))
+LAYERS = ((1, "enc2.conv2"), (2, "enc3.conv2"), (5, "dec3.conv2"), (6, "dec2.conv2"), (7, "dec1.conv2"))
 for rnd in range(2):
-    # (arithmetic code, tile, split override or None = the layer's usual split)
-    for prec, bm, bn, spo in ((4, 128, 128, None), (4, 128, 64, None), (4, 64, 64, None), (4, 64, 64, 1), (4, 256, 64, None),
-                              (5, 128, 64, None), (5, 128, 64, 1), (5, 64, 64, None), (5, 64, 64, 1)):
-        row = f"prec {prec} {bm:3d}x{bn:<3d} s{spo if spo else '*'}"
-        for j, slot, name, sp in LAYERS:
-            sp = spo or sp
+    for prec, bm, bn, fuse in ((4, 128, 128, 1), (4, 64, 128, 1), (4, 128, 64, 1), (4, 64, 64, 1), (4, 256, 64, 1), (5, 128, 64, 1), (5, 64, 64, 1),
+                               (5, 64, 128, 1), (4, 64, 64, 0), (5, 64, 64, 0), (5, 128, 64, 0), (5, 64, 128, 0)):
+        row = f"prec {prec} {bm:3d}x{bn:<3d} fuse {fuse}"
+        for j, name in LAYERS:
             ms, fl = ctypes.c_float(), ctypes.c_double()
-            st = lib.dt_unet_time_conv(h.h, 512, 16, 16, j, slot, bm, bn, sp, prec, 0, 20, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms), ctypes.byref(fl))
+            st = lib.dt_unet_time_conv(h.h, 512, 16, 16, j, 2, bm, bn, 1, prec, fuse, 20, _hip.ptr(ws), ws.numel(), _hip.stream_ptr(), ctypes.byref(ms), ctypes.byref(fl))
             row += f" {name} {ms.value*1e3:6.1f}us ({fl.value/ms.value/1e9:4.0f})" if st == 0 and ms.value > 0 else f" {name}   n/a      "
         print(row, flush=True)
