@@ -24,6 +24,9 @@ def klass(name):
     base, args = m.group(1), m.group(2)
     if args and base.startswith("conv_"):
         a = [x.strip() for x in args.split(",")]
+        # conv_strip_bf16x6_kernel<BM, BN, ABL, KC, WK>: WK > 1 = K split across the waves (named <BM,BN,K{WK}> in the library)
+        if base == "conv_strip_bf16x6_kernel" and len(a) >= 5 and a[4] not in ("1", "1u"):
+            return f"{base}<{a[0]},{a[1]},K{a[4]}>"
         return f"{base}<{a[0]},{a[1]}>"
     return base
 
