@@ -15,11 +15,11 @@ tb = h.time_bias([10, 10], [_hip.COND_NONE, _hip.COND_ONE])
 h.forward(x, tb, 2, 256, tune=False)
 ws = h.workspace(512, 16, 16)
 lib = _hip.load()
-LAYERS = ((0, 2, "enc1.conv2", 1), (1, 1, "enc2.conv1", 1), (1, 2, "enc2.conv2", 1), (2, 1, "enc3.conv1", 2), (6, 1, "dec2.conv1", 4), (6, 2, "dec2.conv2", 2), (7, 1, "dec1.conv1", 2), (7, 2, "dec1.conv2", 2))
+LAYERS = ((0, 2, "enc1.conv2", 1), (1, 1, "enc2.conv1", 1), (1, 2, "enc2.conv2", 1), (2, 1, "enc3.conv1", 2), (6, 1, "dec2.conv1", 4), (6, 2, "dec2.conv2", 2), (7, 1, "dec1.conv1", 2), (7, 2, "dec1.conv2", 2), (3, 1, "enc4.conv1", 8), (5, 1, "dec3.conv1", 8))
 for rnd in range(2):
     # (arithmetic code, tile, split override or None = the layer's usual split)
     for prec, bm, bn, spo in ((4, 128, 128, None), (4, 128, 64, None), (4, 64, 64, None), (4, 64, 64, 1), (4, 256, 64, None),
-                              (5, 128, 64, None), (5, 128, 64, 1), (5, 64, 64, None), (5, 64, 64, 1)):
+                              (5, 128, 64, None), (5, 128, 64, 1), (5, 64, 64, None), (5, 64, 64, 1), (5, 64, 64, 2), (5, 64, 64, 4)):
         row = f"prec {prec} {bm:3d}x{bn:<3d} s{spo if spo else '*'}"
         for j, slot, name, sp in LAYERS:
             sp = spo or sp
