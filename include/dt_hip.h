@@ -111,24 +111,26 @@ int dt_unet_forward(const dt_unet *h, const float *x_dev, int B, int n_pass, int
  * Results are identical up to fp32 summation order (the split changes the grouping of the tap sum). */
 int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
-/* report hook: tile (bm x bn), tap split and arithmetic (0 fp32 MFMA, 1 split-bf16 split in the consumer,
- * 2 split-bf16 fed by LDS-DMA from pre-split plane tensors, 3 split-bf16 "strip" kernel that stages a
- * 3x3 layer's activation tile once per channel chunk for all nine taps, 4 the same with two channel chunks
- * (K = 32) per step; +8 when the block's 1x1 skip is folded into
- * this conv2 launch) in use for block (0..7), slot (0 skip, 1 conv1, 2 conv2);
+/* report hook: tile (bm x bn), tap split and launch kind (0 fp32 MFMA, 1 split-bf16 split in the consumer,
+ * 2 unused (round 1's LDS-DMA variant), 3 split-bf16 "strip" kernel that stages a 3x3 layer's activation tile
+ * once per channel chunk for all nine taps, 4 the same with two channel chunks (K = 32) per step, 5 the strip
+ * kernel with the step's chunks split across the waves of the workgroup -- 64 x 64 wave tiles on 64 x 64 /
+ * 128 x 64 / 64 x 128 workgroup tiles, partial tiles summed in wave order; +8 when the block's 1x1 skip is
+ * folded into this conv2 launch) in use for block (0..7), slot (0 skip, 1 conv1, 2 conv2);
  * bm = 0 means the slot has no launch of its own */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
                         int *splits, int *prec, int *tuned);
 
 /* tuning / test hook: pin the launch choice of one convolution of a forward shape (the other slots keep
- * their current choice).  bm x bn in {64,128}^2;
- * prec 0..4 as reported by dt_unet_conv_choice; splits in {1,3,9} taps, or 1..8 channel-chunk groups for the
- * strip kernel (prec 3; reset to 1 where it does not divide); fuse only for slot 2. */
+ * their current choice).  bm x bn in {64,128}^2, or 256 x 64 for the strip kernels (prec 3 / 4; not 128 x 128 for
+ * prec 5); prec 0..5 as reported by dt_unet_conv_choice; splits in {1,3,9} taps, or 1..8 channel-chunk groups for
+ * the strip kernels (prec >= 3; reset to 1 where it does not divide); fuse only for slot 2. */
 int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn,
                             int splits, int prec, int fuse);
 
 /* tuning aid: time ONE convolution launch (block, slot) of a forward shape under an explicit choice
- * (prec: 0 fp32 MFMA, 1 split-bf16, 3 / 4 split-bf16 strip kernel with K = 16 / 32 per step); averages `reps` launches with HIP events */
+ * (prec: 0 fp32 MFMA, 1 split-bf16, 3 / 4 split-bf16 strip kernel with K = 16 / 32 per step, 5 strip kernel with the
+ * K split across the waves); averages `reps` launches with HIP events */
 int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn,
                       int splits, int prec, int fuse, int reps, void *workspace_dev, size_t workspace_bytes,
                       void *stream, float *ms, double *flops);
