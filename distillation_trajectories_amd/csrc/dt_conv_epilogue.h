@@ -106,6 +106,48 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
     return;                                            // splitk_epilogue_kernel finishes the layer
   }
 
+  // 2x2 max pool of the values the threads just wrote back into the stage (each unit is its thread's own): a 32-row tile
+  // starts on an even picture row and holds whole row pairs (W <= 16), eight pooled pixels per tile
+  auto pool_pass = [&](int mi, float *pool_out) __attribute__((always_inline)) {
+    __syncthreads();
+    const int Wo = p.W >> 1;
+#pragma unroll
+    for (int q = tid; q < WM * 8 * C4; q += 256) {
+      const int pp = q / C4, qc = q % C4, j = pp & 7;
+      const int yy = j / Wo, xx = j - yy * Wo;
+      const int L0 = 2 * yy * p.W + 2 * xx;
+      const int m = m0 + (pp >> 3) * (MI * 32) + mi * 32 + L0;
+      const int qn = n0 + qc * 4;
+      if (m >= p.M || qn >= p.cout_p) continue;
+      const float *s0 = stage + ((pp >> 3) * 32 + L0) * P + qc * 4;
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(s0), b = *reinterpret_cast<const f32x4 *>(s0 + P);
+      const f32x4 c = *reinterpret_cast<const f32x4 *>(s0 + p.W * P), d = *reinterpret_cast<const f32x4 *>(s0 + (p.W + 1) * P);
+      f32x4 mx;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+      const int bimg = m / HW, rem = m - bimg * HW;
+      const int y = rem / p.W, x = rem - y * p.W;
+      *reinterpret_cast<f32x4 *>(pool_out + (((size_t)bimg * (p.H >> 1) + (y >> 1)) * Wo + (x >> 1)) * p.cout_p + qn) = mx;
+    }
+  };
+  // enc1's 1x1 skip of the <= 3-channel image, recomputed from the NCHW image itself: the value added to unit (m, n..n+3)
+  auto x3_skip = [&](int m, int nn) __attribute__((always_inline)) {
+    f32x4 r;
+    const int img = m / p.x3_hw, pix = m - img * p.x3_hw;
+    const float *xr = p.x3 + (size_t)(img % p.x3_imgs) * p.x3_c * p.x3_hw + pix;
+    const float x0 = xr[0], x1 = p.x3_c > 1 ? xr[p.x3_hw] : 0.f, x2 = p.x3_c > 2 ? xr[2 * p.x3_hw] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x4 w3 = *reinterpret_cast<const f32x4 *>(p.w3 + 4 * (nn + e));
+      float rs = w3[3];
+      rs = fmaf(x0, w3[0], rs);
+      if (p.x3_c > 1) rs = fmaf(x1, w3[1], rs);
+      if (p.x3_c > 2) rs = fmaf(x2, w3[2], rs);
+      r[e] = rs;
+    }
+    return r;
+  };
+
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     f32x4 v[U];
@@ -119,6 +161,48 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
     }
 #pragma unroll
     for (int k = 0; k < U; ++k) v[k] = unit(k);
+    if (p.n_dup) {
+      // enc1.conv2 over the B images ONCE for all passes of the step (see ConvParams::tbc): per pass the class bias of the
+      // unit's pixel (corner / edge / interior), BN + ReLU, the shared image skip, the store and the pool
+      const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + nn), sh = *reinterpret_cast<const f32x4 *>(p.shift + nn);
+      f32x4 rs[U];
+      int cls[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        rs[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cls[k] = 0;
+        if (ok[k]) {
+          if (p.x3) rs[k] = x3_skip(mrow[k], nn);
+          const int pix = mrow[k] % HW, y = pix / p.W, x = pix - y * p.W;
+          cls[k] = 3 * (y == 0 ? 0 : (y == p.H - 1 ? 2 : 1)) + (x == 0 ? 0 : (x == p.W - 1 ? 2 : 1));
+        }
+      }
+      for (int pass = 0; pass < p.n_dup; ++pass) {
+        f32x4 o[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          o[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ok[k]) {
+            const size_t mg = (size_t)pass * p.dup_rows + mrow[k];
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(p.tbc + (mg / p.m_per_tb) * p.tb_stride + cls[k] * p.cout_p + n);
+            o[k] = (v[k] + b) * sc + sh;
+            if (p.relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[k][e] = fmaxf(o[k][e], 0.f);
+            }
+            o[k] += rs[k];
+            *reinterpret_cast<f32x4 *>(p.out + mg * p.cout_p + n) = o[k];
+          }
+        }
+        if (p.pool_out) {
+          if (pass) __syncthreads();                   // the previous pass's windows are read
+#pragma unroll
+          for (int k = 0; k < U; ++k) *reinterpret_cast<f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4) = o[k];
+          pool_pass(mi, p.pool_out + (size_t)pass * (p.dup_rows >> 2) * p.cout_p);
+        }
+      }
+      continue;
+    }
     if (p.in2) {
       const f32x4 b2 = *reinterpret_cast<const f32x4 *>(p.bias2 + nn);   // BN/ReLU were applied before the skip walk
 #pragma unroll
@@ -155,25 +239,9 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       for (int k = 0; k < U; ++k) v[k] += a[k];
     }
     if (p.x3) {
-      // enc1's 1x1 skip of the <= 3-channel image, recomputed from the NCHW image itself
-      f32x4 w3[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w3[e] = *reinterpret_cast<const f32x4 *>(p.w3 + 4 * (nn + e));
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        if (!ok[k]) continue;
-        const int img = mrow[k] / p.x3_hw, pix = mrow[k] - img * p.x3_hw;
-        const float *xr = p.x3 + (size_t)(img % p.x3_imgs) * p.x3_c * p.x3_hw + pix;
-        const float x0 = xr[0], x1 = p.x3_c > 1 ? xr[p.x3_hw] : 0.f, x2 = p.x3_c > 2 ? xr[2 * p.x3_hw] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float rs = w3[e][3];
-          rs = fmaf(x0, w3[e][0], rs);
-          if (p.x3_c > 1) rs = fmaf(x1, w3[e][1], rs);
-          if (p.x3_c > 2) rs = fmaf(x2, w3[e][2], rs);
-          v[k][e] += rs;
-        }
-      }
+      for (int k = 0; k < U; ++k)
+        if (ok[k]) v[k] += x3_skip(mrow[k], nn);
     }
     if (p.head_out) {
       // final 1x1 head on the rows this workgroup holds completely: C4 consecutive lanes own one row
@@ -211,30 +279,9 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
     for (int k = 0; k < U; ++k)
       if (ok[k]) *reinterpret_cast<f32x4 *>(p.out + (size_t)mrow[k] * p.cout_p + n) = v[k];
     if (p.pool_out) {
-      // final values back into the stage (each unit is this thread's own), then 2x2 windows: a 32-row tile starts on
-      // an even picture row and holds whole row pairs (W <= 16), eight pooled pixels per tile
 #pragma unroll
       for (int k = 0; k < U; ++k) *reinterpret_cast<f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4) = v[k];
-      __syncthreads();
-      const int Wo = p.W >> 1;
-#pragma unroll
-      for (int q = tid; q < WM * 8 * C4; q += 256) {
-        const int pp = q / C4, qc = q % C4, j = pp & 7;
-        const int yy = j / Wo, xx = j - yy * Wo;
-        const int L0 = 2 * yy * p.W + 2 * xx;
-        const int m = m0 + (pp >> 3) * (MI * 32) + mi * 32 + L0;
-        const int qn = n0 + qc * 4;
-        if (m >= p.M || qn >= p.cout_p) continue;
-        const float *s0 = stage + ((pp >> 3) * 32 + L0) * P + qc * 4;
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(s0), b = *reinterpret_cast<const f32x4 *>(s0 + P);
-        const f32x4 c = *reinterpret_cast<const f32x4 *>(s0 + p.W * P), d = *reinterpret_cast<const f32x4 *>(s0 + (p.W + 1) * P);
-        f32x4 mx;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
-        const int bimg = m / HW, rem = m - bimg * HW;
-        const int y = rem / p.W, x = rem - y * p.W;
-        *reinterpret_cast<f32x4 *>(p.pool_out + (((size_t)bimg * (p.H >> 1) + (y >> 1)) * Wo + (x >> 1)) * p.cout_p + qn) = mx;
-      }
+      pool_pass(mi, p.pool_out);
     }
   }
 }

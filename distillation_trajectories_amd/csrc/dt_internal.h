@@ -112,6 +112,12 @@ struct ConvParams {
   const float *head_w, *head_b;
   float *head_out;
   int head_c, head_cin;
+  // enc1.conv2 when the n_dup passes of a CFG step share the block input (n_dup > 0): the launch covers the B images
+  // once, WITHOUT the time bias in its input; per pass the epilogue adds that pass's class-bias row (tbc: nine
+  // per-channel vectors -- corner / edge / interior -- per time-bias row, see tap_bias_kernel) and writes out / pool_out
+  // at row offset pass * dup_rows (pass * dup_rows / 4 for the pooled tensor)
+  const float *tbc;
+  int n_dup, dup_rows;
   int ablate;          // timing experiments only (wrong results): 1 no barrier, 2 no LDS reads, 3 no MFMA, 4 no staging
 };
 
@@ -138,6 +144,7 @@ int launch_pack_linear_rows(const float *w, const float *b, float *wp, float *bp
 int launch_first_conv(const float *x, const float *wf, const float *scale, const float *shift, const float *tb, int tb_stride,
                       int tb_div, float *out, int B, int n_pass, int C, int H, int W, int cout, int cout_p, hipStream_t s);
 int launch_pack_first_conv(const float *w_oihw, float *wf, int cout, int C, int cout_p, hipStream_t s);
+int launch_pack_tap_major(const float *w_oihw, float *w2t, int cout, int cin, int cp, hipStream_t s);   // [n][ci][3][3] -> [tap][ci][cp]
 int launch_maxpool(const float *in, float *out, int Bt, int H, int W, int cp, hipStream_t s);
 // skip == nullptr: only the upsampled channels are written (the consumers read the skip half in place)
 int launch_upcat(const float *lo, const float *skip, float *out, int Bt, int h, int w, int c1p, int c2p,
@@ -152,8 +159,11 @@ struct TembWeights {
   const float *w1, *b1;      // time_mlp.1  [D][D]
   const float *wc0, *bc0;    // cond_emb.0  [D][1]
   const float *wc2, *bc2;    // cond_emb.2  [D][D]
-  const float *wt, *bt;      // concatenated per-block time_mlp rows [tb_stride][D] (zero rows on padding)
-  int D, half, tb_stride;
+  const float *wt, *bt;      // concatenated per-block time_mlp rows [tb_cols][D] (zero rows on padding)
+  int D, half, tb_stride;    // tb_stride: floats per output row
+  int tb_cols;               // projected channels per row (sum of the blocks' padded widths); the rest of a row:
+  const float *w2t;          // enc1.conv2's weights as [tap][ci][c0p] (nullptr: no class-bias columns)
+  int c0p;                   // enc1's padded width; columns [tb_cols, tb_cols + 9 c0p) hold the class biases
 };
 int launch_time_bias(const TembWeights &tw, const int32_t *t, const float *cond, const uint8_t *present, int rows,
                      float *out, hipStream_t s);

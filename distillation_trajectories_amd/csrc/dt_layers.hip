@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float *__restrict
     const int pix = y * W + x0;
     for (int pass = 0; pass < n_pass; ++pass) {
       const int bt = pass * B + b;
-      const f32x4 t = *reinterpret_cast<const f32x4 *>(tb + (size_t)(bt / tb_div) * tb_stride + q * 4);
+      const f32x4 t = tb ? *reinterpret_cast<const f32x4 *>(tb + (size_t)(bt / tb_div) * tb_stride + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int px = 0; px < PX; ++px)
         *reinterpret_cast<f32x4 *>(out + ((size_t)bt * HW + pix + px) * cp + q * 4) = acc[px] + t;
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(1024) void time_bias_kernel(const TembWeights tw, c
   }
   __syncthreads();
   float *orow = out + (size_t)row * tw.tb_stride;
-  const int per = (tw.tb_stride + slices - 1) / slices;
-  const int lo = slice * per, hi = lo + per < tw.tb_stride ? lo + per : tw.tb_stride;
+  const int per = (tw.tb_cols + slices - 1) / slices;
+  const int lo = slice * per, hi = lo + per < tw.tb_cols ? lo + per : tw.tb_cols;
   for (int o = lo + wave * G; o < hi; o += n_waves * G) {
     const int cnt = hi - o < G ? hi - o : G;
     float a[G];
@@ -342,12 +342,65 @@ __global__ __launch_bounds__(1024) void time_bias_kernel(const TembWeights tw, c
   }
 }
 
+// Class biases of enc1.conv2 (reference models.py:66-79: h = relu(bn1(conv1 x)) + b, then conv2(h)).  conv2 is linear and
+// b is constant over the picture, so conv2(a + b) = conv2(a) + sum over the taps that fall INSIDE the picture of
+// W2[n][ci][tap] b[ci]: nine per-channel vectors (top / middle / bottom row x left / middle / right column), which is what
+// lets the CFG passes of a step -- same x, different b -- share ONE conv2 launch over the B images.
+// out row layout: [tb_cols projected channels | 9 x c0p class biases], class = 3 * (y == 0 ? 0 : y == H-1 ? 2 : 1) + same for x.
+__global__ __launch_bounds__(1024) void tap_bias_kernel(const TembWeights tw, float *__restrict__ out) {
+  extern __shared__ float bsm[];            // the row's enc1 time bias [c0p] | per-tap sums [9][c0p]
+  const int c0p = tw.c0p;
+  float *tsum = bsm + c0p;
+  float *orow = out + (size_t)blockIdx.x * tw.tb_stride;
+  for (int i = threadIdx.x; i < c0p; i += blockDim.x) bsm[i] = orow[i];      // enc1 is block 0: columns [0, c0p)
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * c0p; i += blockDim.x) {                  // (tap, n): consecutive threads read consecutive n
+    const int tap = i / c0p, n = i - tap * c0p;
+    const float *w = tw.w2t + (size_t)tap * c0p * c0p + n;
+    float a = 0.f;
+    for (int ci = 0; ci < c0p; ++ci) a = fmaf(w[(size_t)ci * c0p], bsm[ci], a);
+    tsum[i] = a;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * c0p; i += blockDim.x) {                  // (class, n)
+    const int cls = i / c0p, n = i - cls * c0p;
+    const int cy = cls / 3, cx = cls - 3 * cy;
+    float a = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const bool in = !(cy == 0 && dy < 0) && !(cy == 2 && dy > 0) && !(cx == 0 && dx < 0) && !(cx == 2 && dx > 0);
+      if (in) a += tsum[tap * c0p + n];
+    }
+    orow[tw.tb_cols + i] = a;
+  }
+}
+
 int launch_time_bias(const TembWeights &tw, const int32_t *t, const float *cond, const uint8_t *present, int rows,
                      float *out, hipStream_t s) {
   if (rows <= 0) return DT_OK;
   const int slices = rows >= 512 ? 1 : (rows >= 64 ? 4 : 8);      // few rows: spread the long stage over more CUs
-  ProfileScope prof(KC_TIME_BIAS, 2.0 * rows * tw.D * (2.0 * tw.D + tw.tb_stride), 4.0 * rows * tw.tb_stride, s);
+  ProfileScope prof(KC_TIME_BIAS, 2.0 * rows * tw.D * (2.0 * tw.D + tw.tb_cols) + (tw.w2t ? 18.0 * rows * tw.c0p * tw.c0p : 0.0),
+                    4.0 * rows * tw.tb_stride, s);
   time_bias_kernel<<<rows * slices, 1024, 3 * tw.D * sizeof(float), s>>>(tw, t, cond, present, out, slices);
+  DT_LAUNCH_CHECK();
+  if (tw.w2t) {
+    tap_bias_kernel<<<rows, 1024, 10 * tw.c0p * sizeof(float), s>>>(tw, out);
+    DT_LAUNCH_CHECK();
+  }
+  return DT_OK;
+}
+
+// conv2.weight OIHW [cout][cin][3][3] -> w2t[tap][ci][cp] (zero on padding rows / columns)
+__global__ void pack_tap_major_kernel(const float *__restrict__ w, float *__restrict__ w2t, int cout, int cin, int cp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * cp * cp) return;
+  const int n = i % cp, ci = (i / cp) % cp, tap = i / (cp * cp);
+  w2t[i] = (n < cout && ci < cin) ? w[((size_t)n * cin + ci) * 9 + tap] : 0.f;
+}
+
+int launch_pack_tap_major(const float *w_oihw, float *w2t, int cout, int cin, int cp, hipStream_t s) {
+  pack_tap_major_kernel<<<(9 * cp * cp + 255) / 256, 256, 0, s>>>(w_oihw, w2t, cout, cin, cp);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

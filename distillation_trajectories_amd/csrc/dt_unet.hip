@@ -122,6 +122,11 @@ struct dt_unet {
   mutable std::mutex graph_mu;
   int precision;          // DT_PREC_*: which convolution arithmetic the heuristic / autotuner may use
   bool head_fusion = true;   // dec1.conv2's epilogue evaluates the final 1x1 head (dt_unet_set_head_fusion)
+  // enc1 runs ONCE per step for all CFG passes (they share x): conv1 without the time bias over the B images, conv2 over the
+  // B images with the passes' time biases entering as class-bias rows in its epilogue (tap_bias_kernel); DT_NO_SHARED_ENC1=1
+  // at create time keeps the per-pass formulation (A/B runs, and the form the reference's operation order follows literally)
+  bool share_enc1 = true;
+  int tb_cols = 0;           // projected channels of a time-bias row; the class-bias columns follow
   dt_unet_desc desc;
   BlockW blk[kBlocks];
   int cp[4];              // padded dims
@@ -190,7 +195,8 @@ const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W) {
 // Parameters of conv slot `slot` (0 = 1x1 skip, 1 = conv1, 2 = conv2) of block j; returns false when the
 // block has no such launch (identity skips, and enc1 whose skip is recomputed in conv2's epilogue).
 bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, const Plan &pl, int Bt, const float *tb,
-               int tb_div, const ConvChoice *choice, ConvParams &p, int x_imgs = 1) {
+               int tb_div, const ConvChoice *choice, ConvParams &p, int x_imgs = 0) {
+  if (x_imgs <= 0) x_imgs = Bt % 2 == 0 ? Bt / 2 : Bt;   // tuning / reporting contexts: the sampler's two-pass CFG shape
   const BlockW &k = u->blk[j];
   const int h = pl.H[j], w = pl.W[j];
   const bool dot = h == 1 && w == 1;   // a 1x1 image only ever sees the centre tap of a padded 3x3 kernel
@@ -223,6 +229,10 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
       // the C-channel skip of enc1 is recomputed in the epilogue from the patches' centre taps (k = 9c+4)
       p.x3 = in; p.w3 = k.w3; p.x3_hw = h * w; p.x3_imgs = x_imgs; p.x3_c = u->desc.channels;   // `in` is the NCHW image
       taps = 1;   // keeps the fused (non-split) epilogue
+      if (u->share_enc1 && Bt % x_imgs == 0) {   // one launch over the x_imgs images for all Bt / x_imgs passes
+        p.M = x_imgs * h * w;
+        p.n_dup = Bt / x_imgs; p.dup_rows = p.M; p.tbc = tb + u->tb_cols;
+      }
     } else {
       p.add = k.has_res ? ws + pl.r[j] : in;   // identity skip: cin_p == cout_p
     }
@@ -288,8 +298,9 @@ int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &p
   const bool in_place = concat_in_place(u, j, ws, pl, Bt, tb, tb_div, tuned);
   if (j == 0) {
     const BlockW &k = u->blk[0];
-    const int st = launch_first_conv(in, k.w1, k.s1, k.h1, tb + k.tb_off, u->tb_stride, tb_div, ws + pl.h[0], x_imgs, Bt / x_imgs,
-                                     u->desc.channels, pl.H[0], pl.W[0], k.cout, k.cout_p, s);
+    const bool shared = u->share_enc1 && Bt % x_imgs == 0;   // then the passes' time biases enter in conv2's epilogue
+    const int st = launch_first_conv(in, k.w1, k.s1, k.h1, shared ? nullptr : tb + k.tb_off, u->tb_stride, tb_div, ws + pl.h[0], x_imgs,
+                                     shared ? 1 : Bt / x_imgs, u->desc.channels, pl.H[0], pl.W[0], k.cout, k.cout_p, s);
     if (st) return st;
   }
   for (int slot = 0; slot < 3; ++slot) {
@@ -421,7 +432,11 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
     k.tb_off = tb;
     tb += k.cout_p;
   }
-  u->tb_stride = tb;
+  u->share_enc1 = getenv("DT_NO_SHARED_ENC1") == nullptr;
+  const int c0p = u->blk[0].cout_p;
+  u->tb_cols = tb;
+  u->tb_stride = tb + (u->share_enc1 ? 9 * c0p : 0);          // [projected channels | nine class-bias vectors of enc1.conv2]
+  const size_t o_w2t = u->share_enc1 ? bump.take((size_t)9 * c0p * c0p) : 0;
   const int half = (D / 2 > 1 ? D / 2 : 1);
   const size_t o_wt = bump.take((size_t)tb * D), o_bt = bump.take(tb);
   const size_t o_w1g = bump.take((size_t)D * D), o_b1g = bump.take(D), o_wc0 = bump.take(D), o_bc0 = bump.take(D);
@@ -459,6 +474,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
     if (!st && k.has_res && j > 0)
       st = launch_pack_conv_bf16x3(t[DT_BT_RES_W], k.wrb, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
     if (!st && j == 0) st = launch_pack_res3(t[DT_BT_RES_W], t[DT_BT_RES_B], k.w3, k.cout, C, k.n_p, s);
+    if (!st && j == 0 && u->share_enc1) st = launch_pack_tap_major(t[DT_BT_CONV2_W], S + o_w2t, k.cout, k.cout, k.cout_p, s);
     if (!st) st = launch_fold_bn(t[DT_BT_CONV1_B], t[DT_BT_BN1_G], t[DT_BT_BN1_B], t[DT_BT_BN1_MEAN], t[DT_BT_BN1_VAR],
                                  k.s1, k.h1, k.cout, k.n_p, s);
     if (!st) st = launch_fold_bn(t[DT_BT_CONV2_B], t[DT_BT_BN2_G], t[DT_BT_BN2_B], t[DT_BT_BN2_MEAN], t[DT_BT_BN2_VAR],
@@ -475,7 +491,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   copy(o_fw, gt[DT_GT_FINAL_W], (size_t)C * d[0]); copy(o_fb, gt[DT_GT_FINAL_B], C);
   if (st != DT_OK) { (void)hipFree(u->slab); delete u; return st; }
   u->tw = TembWeights{S + o_fr, S + o_w1g, S + o_b1g, S + o_wc0, S + o_bc0, S + o_wc2, S + o_bc2, S + o_wt, S + o_bt,
-                      D, half, tb};
+                      D, half, u->tb_stride, tb, u->share_enc1 ? S + o_w2t : nullptr, c0p};
   u->final_w = S + o_fw; u->final_b = S + o_fb;
   *out = u;
   return DT_OK;

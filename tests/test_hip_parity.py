@@ -293,7 +293,23 @@ def test_time_bias_rows(gpu_models):
         pad = (cout + 15) // 16 * 16
         assert not got[:, off + cout: off + pad].any()
         off += pad
-    assert off == h.tb_stride
+    # the rest of a row: enc1.conv2's nine class-bias vectors (the spatially constant time bias under a zero-padded 3x3
+    # conv: sum over the taps inside the picture of W2[n][ci][tap] b[ci]; corner / edge / interior of the picture)
+    c0 = sd["enc1.conv2.weight"].shape[0]
+    c0p = (c0 + 15) // 16 * 16
+    assert h.tb_stride == off + 9 * c0p
+    w2 = sd["enc1.conv2.weight"].double()                                  # [n][ci][3][3]
+    for r in range(len(ts)):
+        b = got[r, :c0].double()
+        per_tap = torch.einsum("nckl,c->nkl", w2, b)                       # [n][dy+1][dx+1]
+        for cy in range(3):
+            for cx in range(3):
+                rows = [d for d in range(3) if not (cy == 0 and d == 0) and not (cy == 2 and d == 2)]
+                cols = [d for d in range(3) if not (cx == 0 and d == 0) and not (cx == 2 and d == 2)]
+                want = per_tap[:, rows][:, :, cols].sum(dim=(1, 2))
+                lo = off + (cy * 3 + cx) * c0p
+                assert_close(got[r, lo: lo + c0].numpy(), want.float().numpy(), rtol=2e-5, atol=2e-5, what=f"class bias {cy}{cx} row {r}")
+                assert not got[r, lo + c0: lo + c0p].any()
 
 
 # ------------------------------------------------------------------ fused update: bit exact
