@@ -87,11 +87,13 @@ int dt_unet_create(const dt_unet_desc *desc,
                    void *stream, dt_unet **out);
 void dt_unet_destroy(dt_unet *h);
 
-/* floats per row of the time-bias table (sum of padded out-channels of the 8 blocks) */
+/* floats per row of the time-bias table: the padded out-channels of the 8 blocks, followed by the nine class-bias
+ * vectors of enc1.conv2 (9 x enc1's padded width: the row's enc1 time bias pushed through conv2's in-picture taps for
+ * corner / edge / interior pixels, which is what lets the n_pass passes of a forward share ONE enc1 launch) */
 int dt_unet_time_bias_stride(const dt_unet *h);
 
-/* models.py:175-185 + the per-block ReLU(Linear(temb)) of models.py:66-77, evaluated once per
- * (t, cond) row instead of once per sample.  cond_dev[r] is the scalar condition of row r;
+/* models.py:175-185 + the per-block ReLU(Linear(temb)) of models.py:66-77 (+ the class biases above), evaluated once
+ * per (t, cond) row instead of once per sample.  cond_dev[r] is the scalar condition of row r;
  * cond_present_dev[r]==0 means cond=None (either array may be NULL: no cond / all present). */
 int dt_unet_time_bias(const dt_unet *h, const int32_t *t_dev, const float *cond_dev,
                       const uint8_t *cond_present_dev, int rows, float *out_dev, void *stream);
