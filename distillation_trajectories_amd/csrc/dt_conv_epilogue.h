@@ -191,7 +191,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
               for (int e = 0; e < 4; ++e) o[k][e] = fmaxf(o[k][e], 0.f);
             }
             o[k] += rs[k];
-            *reinterpret_cast<f32x4 *>(p.out + mg * p.cout_p + n) = o[k];
+            if (!p.skip_out) *reinterpret_cast<f32x4 *>(p.out + mg * p.cout_p + n) = o[k];
           }
         }
         if (p.pool_out) {

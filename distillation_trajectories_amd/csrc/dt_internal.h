@@ -118,6 +118,7 @@ struct ConvParams {
   // at row offset pass * dup_rows (pass * dup_rows / 4 for the pooled tensor)
   const float *tbc;
   int n_dup, dup_rows;
+  int skip_out;        // n_dup mode: do not store `out` (enc1's full-resolution output has no reader but the pool)
   int ablate;          // timing experiments only (wrong results): 1 no barrier, 2 no LDS reads, 3 no MFMA, 4 no staging
 };
 

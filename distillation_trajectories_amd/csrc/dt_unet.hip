@@ -232,6 +232,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
       if (u->share_enc1 && Bt % x_imgs == 0) {   // one launch over the x_imgs images for all Bt / x_imgs passes
         p.M = x_imgs * h * w;
         p.n_dup = Bt / x_imgs; p.dup_rows = p.M; p.tbc = tb + u->tb_cols;
+        p.skip_out = u->head_fusion ? 1 : 0;   // decided below once pool_out is known: only the pool reads enc1's output
       }
     } else {
       p.add = k.has_res ? ws + pl.r[j] : in;   // identity skip: cin_p == cout_p
@@ -259,6 +260,7 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   // encoder blocks enc1..enc4 feed a 2x2 max pool: folded into this launch's staged epilogue where a 32-row tile holds
   // whole row pairs (W a power of two <= 16); split launches pool in their slab-summing epilogue kernel instead
   if (slot == 2 && j <= 3 && h % 2 == 0 && w % 2 == 0 && (c.splits > 1 || (w <= 16 && (w & (w - 1)) == 0))) p.pool_out = ws + pl.pool[j];
+  if (!p.pool_out) p.skip_out = 0;            // a separate pooling launch reads the full-resolution output
   if (c.prec >= 1) p.w = slot == 0 ? k.wrb : (slot == 1 ? k.w1b : k.w2b);
   // dec1.conv2 also evaluates the final 1x1 head when its workgroups hold whole rows (one N tile, no split): the head
   // is dec1's only consumer, so dec1's own output is then never written

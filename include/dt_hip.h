@@ -146,9 +146,9 @@ int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block
 enum { DT_PREC_FP32 = 0, DT_PREC_SPLIT_BF16 = 1, DT_PREC_AUTO = 2 };
 int dt_unet_set_precision(dt_unet *h, int precision);
 
-/* test hook: dec1.conv2 normally evaluates the final 1x1 head in its own epilogue and then never writes dec1's output
- * (models.py:218-224: the head is its only consumer); on == 0 restores the separate head launch so that
- * dt_unet_debug_activation can show block 7.  Default on. */
+/* test hook: dec1.conv2 normally evaluates the final 1x1 head in its own epilogue and then never writes dec1's output,
+ * and enc1.conv2 writes only its pooled output (nothing else reads enc1's full-resolution tensor); on = 0 materialises
+ * both block outputs (separate head launch) so that dt_unet_debug_activation can expose every block */
 int dt_unet_set_head_fusion(dt_unet *h, int on);
 
 /* test hook: float offset / padded channel count of a block output inside the workspace
