@@ -191,6 +191,9 @@ class PairWorkload:
                             f"+ time/cond embedding rows + trajectory metrics of the {self.B} pairs",
                 "batch_per_gpu": self.B, "timesteps": self.T, "image": [C, self.H, self.H],
                 "guidance_scale": s["guidance"], "unet_passes_per_step": 2,
+                # both passes are computed every step; enc1 (whose input x the passes share) runs once and emits both passes'
+                # outputs from one accumulator tile unless DT_NO_SHARED_ENC1=1
+                "enc1_shared_by_cfg_passes": os.environ.get("DT_NO_SHARED_ENC1") is None,
                 "parallelism": f"sample-sharded x{world}, RCCL all-gather of metrics",
                 "streams_per_gpu": {"teacher_sub_batches": len(self.parts[0]), "student_sub_batches": len(self.parts[1])}}
 

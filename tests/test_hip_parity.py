@@ -173,6 +173,30 @@ def test_unet_forward_large_batch_properties(gpu_models):
     h.set_precision(_hip.PREC_AUTO)
 
 
+def test_shared_enc1_matches_per_pass_form(gpu_models, monkeypatch):
+    """The CFG passes share x, so enc1 runs once for both (class-bias rows in conv2's epilogue, DESIGN section 3);
+    DT_NO_SHARED_ENC1=1 at create time keeps one enc1 per pass.  Both forms against each other and the oracle."""
+    m = gpu_models(0.5)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    B = 6
+    x = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(11)).to(DEV)
+    h_shared = engine.UNetHandle(m.state_dict(), DEV)
+    monkeypatch.setenv("DT_NO_SHARED_ENC1", "1")
+    h_plain = engine.UNetHandle(m.state_dict(), DEV)
+    monkeypatch.delenv("DT_NO_SHARED_ENC1")
+    assert h_shared.tb_stride > h_plain.tb_stride                 # only the shared form carries the class-bias columns
+    outs = []
+    for h in (h_shared, h_plain):
+        tb = h.time_bias([23, 23], [_hip.COND_NONE, _hip.COND_ONE])
+        outs.append(h.forward(x, tb, 2, B, tune=False).cpu().numpy())
+    assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5, what="shared vs per-pass enc1")
+    with torch.no_grad():
+        want_u = unet_ref.unet_forward(sd, x.cpu(), torch.full((B,), 23), None).numpy()
+        want_c = unet_ref.unet_forward(sd, x.cpu(), torch.full((B,), 23), torch.ones(B, 1)).numpy()
+    assert_close(outs[0][:B], want_u, what="shared enc1, unconditional pass")
+    assert_close(outs[0][B:], want_c, what="shared enc1, conditional pass")
+
+
 def test_conv_tile_variants_match_oracle(gpu_models):
     """Every launch shape of the conv kernels (tile, wave layout, tap split, arithmetic, fused skip), pinned one
     layer at a time through dt_unet_set_conv_choice, against the oracle forward."""
