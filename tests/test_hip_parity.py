@@ -173,6 +173,29 @@ def test_unet_forward_large_batch_properties(gpu_models):
     h.set_precision(_hip.PREC_AUTO)
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+def test_one_and_two_channel_images(channels):
+    """MNIST-shaped (1-channel) and 2-channel inputs: the first-layer kernel, enc1's image skip in conv2's epilogue,
+    the 1x1 head and the fused update all take the channel count at run time (reference models.py:138, 218)."""
+    from distillation_trajectories_amd.config import Config
+    from distillation_trajectories_amd.models import DiffusionUNet
+    from distillation_trajectories_amd.synthetic import make_model
+    cfg = Config(); cfg.image_size = 16; cfg.channels = channels
+    m = make_model(DiffusionUNet, cfg, 0.2, seed=900 + channels).to(DEV)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    h = engine.UNetHandle.for_module(m)
+    B = 5
+    x = torch.randn(B, channels, 16, 16, generator=torch.Generator().manual_seed(channels)).to(DEV)
+    tb = h.time_bias([31, 31], [_hip.COND_NONE, _hip.COND_ONE])
+    got = h.forward(x, tb, 2, B, tune=False).cpu().numpy()
+    assert got.shape == (2 * B, channels, 16, 16)
+    with torch.no_grad():
+        want_u = unet_ref.unet_forward(sd, x.cpu(), torch.full((B,), 31), None).numpy()
+        want_c = unet_ref.unet_forward(sd, x.cpu(), torch.full((B,), 31), torch.ones(B, 1)).numpy()
+    assert_close(got[:B], want_u, what=f"{channels}-channel, unconditional")
+    assert_close(got[B:], want_c, what=f"{channels}-channel, conditional")
+
+
 def test_shared_enc1_matches_per_pass_form(gpu_models, monkeypatch):
     """The CFG passes share x, so enc1 runs once for both (class-bias rows in conv2's epilogue, DESIGN section 3);
     DT_NO_SHARED_ENC1=1 at create time keeps one enc1 per pass.  Both forms against each other and the oracle."""
