@@ -12,7 +12,7 @@ COND_NONE, COND_ZERO, COND_ONE = 0, 1, 2
 RULE_ENGINE, RULE_PSAMPLE, RULE_MANAGER = 0, 1, 2
 PREC_FP32, PREC_SPLIT_BF16, PREC_AUTO = 0, 1, 2
 BT_COUNT, GT_COUNT, N_BLOCKS = 16, 9, 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipLibraryError(RuntimeError):

@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define DT_ABI_VERSION 1
+/* 2: time-bias rows carry enc1.conv2's class-bias columns (dt_unet_time_bias_stride), launch kind 5 and the 256 x 64 tile
+ * in the conv-choice hooks; the exported symbols are those of version 1 */
+#define DT_ABI_VERSION 2
 
 enum {
   DT_OK = 0,
