@@ -145,7 +145,7 @@ int launch_splitk_epilogue(const ConvParams &p, hipStream_t s);
 int launch_conv(const ConvParams &p, hipStream_t s) {
   if (!p.in || !p.w || !p.scale || !p.shift || !p.out) return DT_E_NULL;
   if (p.cin_p % 16 || p.cout_p % 16 || p.n_p % kNPad || p.M <= 0) return DT_E_SHAPE;
-  if ((long long)p.M * p.cin_p >= (1ll << 31) || (long long)p.M * p.cout_p >= (1ll << 31)) return DT_E_SHAPE;
+  if ((long long)p.M * p.cin_p >= (1ll << 31) || (long long)p.M * p.cout_p * (p.n_dup > 1 ? p.n_dup : 1) >= (1ll << 31)) return DT_E_SHAPE;
   int bm = p.bm, bn = p.bn;
   if (!bm || !bn) {
     const ConvChoice c = heuristic_choice(p.M, p.n_p, 1);

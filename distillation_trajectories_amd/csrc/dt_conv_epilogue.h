@@ -64,6 +64,12 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
   constexpr int COPY = WM * 32 * P;
   const int tid = threadIdx.x;
   const int HW = p.H * p.W;
+  // pictures are powers of two in every benchmark shape: row -> (picture, y, x) by shifts there (an integer division by a run-time
+  // value is ~30 VALU instructions, and the fused pool / image-skip / class-bias paths do several per unit)
+  const bool pow2 = (p.W & (p.W - 1)) == 0 && (HW & (HW - 1)) == 0;
+  const int w_sh = 31 - __builtin_clz(p.W), hw_sh = 31 - __builtin_clz(HW);
+  auto div_hw = [&](int m) { return pow2 ? m >> hw_sh : m / HW; };
+  auto div_w = [&](int r) { return pow2 ? r >> w_sh : r / p.W; };
   const bool slab_mode = p.splits > 1;
   const size_t slab_stride = (size_t)p.M * p.cout_p;
   // ---- this thread's units of a pass: row = tid / C4 + k * (256 / C4), four consecutive channels
@@ -108,37 +114,41 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
 
   // 2x2 max pool of the values the threads just wrote back into the stage (each unit is its thread's own): a 32-row tile
   // starts on an even picture row and holds whole row pairs (W <= 16), eight pooled pixels per tile
-  auto pool_pass = [&](int mi, float *pool_out) __attribute__((always_inline)) {
+  // (n_src > 1: the passes of a dual-output layer, pass i staged at src + i * src_pitch and pooled to pool_out + i * out_pitch)
+  auto pool_pass = [&](int mi, float *pool_out, const float *src, int n_src, int src_pitch, size_t out_pitch) __attribute__((always_inline)) {
     __syncthreads();
     const int Wo = p.W >> 1;
-#pragma unroll
-    for (int q = tid; q < WM * 8 * C4; q += 256) {
+    for (int q0 = tid; q0 < n_src * WM * 8 * C4; q0 += 256) {
+      const int pass = q0 / (WM * 8 * C4), q = q0 - pass * (WM * 8 * C4);
       const int pp = q / C4, qc = q % C4, j = pp & 7;
-      const int yy = j / Wo, xx = j - yy * Wo;
+      const int yy = pow2 ? j >> (w_sh - 1) : j / Wo, xx = j - yy * Wo;
       const int L0 = 2 * yy * p.W + 2 * xx;
       const int m = m0 + (pp >> 3) * (MI * 32) + mi * 32 + L0;
       const int qn = n0 + qc * 4;
       if (m >= p.M || qn >= p.cout_p) continue;
-      const float *s0 = stage + ((pp >> 3) * 32 + L0) * P + qc * 4;
+      const float *s0 = src + pass * src_pitch + ((pp >> 3) * 32 + L0) * P + qc * 4;
       const f32x4 a = *reinterpret_cast<const f32x4 *>(s0), b = *reinterpret_cast<const f32x4 *>(s0 + P);
       const f32x4 c = *reinterpret_cast<const f32x4 *>(s0 + p.W * P), d = *reinterpret_cast<const f32x4 *>(s0 + (p.W + 1) * P);
       f32x4 mx;
 #pragma unroll
       for (int e = 0; e < 4; ++e) mx[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
-      const int bimg = m / HW, rem = m - bimg * HW;
-      const int y = rem / p.W, x = rem - y * p.W;
-      *reinterpret_cast<f32x4 *>(pool_out + (((size_t)bimg * (p.H >> 1) + (y >> 1)) * Wo + (x >> 1)) * p.cout_p + qn) = mx;
+      const int bimg = div_hw(m), rem = m - bimg * HW;
+      const int y = div_w(rem), x = rem - y * p.W;
+      *reinterpret_cast<f32x4 *>(pool_out + pass * out_pitch + (((size_t)bimg * (p.H >> 1) + (y >> 1)) * Wo + (x >> 1)) * p.cout_p + qn) = mx;
     }
   };
   // enc1's 1x1 skip of the <= 3-channel image, recomputed from the NCHW image itself: the value added to unit (m, n..n+3)
-  auto x3_skip = [&](int m, int nn) __attribute__((always_inline)) {
+  f32x4 w3r[4];                                        // this thread's four channels: weights of the <= 3 image channels + bias
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w3r[e] = p.x3 ? *reinterpret_cast<const f32x4 *>(p.w3 + 4 * (nn + e)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  auto x3_skip = [&](int m, int) __attribute__((always_inline)) {
     f32x4 r;
-    const int img = m / p.x3_hw, pix = m - img * p.x3_hw;
-    const float *xr = p.x3 + (size_t)(img % p.x3_imgs) * p.x3_c * p.x3_hw + pix;
+    const int img = div_hw(m), pix = m - img * HW;                 // (x3_hw == H * W)
+    const float *xr = p.x3 + (size_t)(img < p.x3_imgs ? img : img % p.x3_imgs) * p.x3_c * p.x3_hw + pix;
     const float x0 = xr[0], x1 = p.x3_c > 1 ? xr[p.x3_hw] : 0.f, x2 = p.x3_c > 2 ? xr[2 * p.x3_hw] : 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const f32x4 w3 = *reinterpret_cast<const f32x4 *>(p.w3 + 4 * (nn + e));
+      const f32x4 w3 = w3r[e];
       float rs = w3[3];
       rs = fmaf(x0, w3[0], rs);
       if (p.x3_c > 1) rs = fmaf(x1, w3[1], rs);
@@ -165,17 +175,47 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       // enc1.conv2 over the B images ONCE for all passes of the step (see ConvParams::tbc): per pass the class bias of the
       // unit's pixel (corner / edge / interior), BN + ReLU, the shared image skip, the store and the pool
       const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + nn), sh = *reinterpret_cast<const f32x4 *>(p.shift + nn);
+      // (rows are clamped instead of branched over, so that every unit's loads are issued before the first is waited for)
       f32x4 rs[U];
-      int cls[U];
+      int cls[U], mc[U];
 #pragma unroll
       for (int k = 0; k < U; ++k) {
-        rs[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        cls[k] = 0;
-        if (ok[k]) {
-          if (p.x3) rs[k] = x3_skip(mrow[k], nn);
-          const int pix = mrow[k] % HW, y = pix / p.W, x = pix - y * p.W;
-          cls[k] = 3 * (y == 0 ? 0 : (y == p.H - 1 ? 2 : 1)) + (x == 0 ? 0 : (x == p.W - 1 ? 2 : 1));
+        mc[k] = ok[k] ? mrow[k] : m0;
+        const int pix = mc[k] - div_hw(mc[k]) * HW, y = div_w(pix), x = pix - y * p.W;
+        cls[k] = 3 * (y == 0 ? 0 : (y == p.H - 1 ? 2 : 1)) + (x == 0 ? 0 : (x == p.W - 1 ? 2 : 1));
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) rs[k] = p.x3 ? x3_skip(mc[k], nn) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.n_dup == 2 && p.dup_stage2 && p.pool_out) {
+        // two passes (the CFG pair), room for a second stage behind the partial-tile copies: both passes' values are formed
+        // together (their class-bias loads overlap), staged side by side and pooled in ONE sweep -- two barriers per 32-row
+        // pass instead of six (per-workgroup timelines put the pass-after-pass form at 27 us per 256 x 64 tile)
+        float *stage2 = stage + WK * COPY;
+        f32x4 b0[U], b1[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          // (32-bit row arithmetic: launch_conv bounds n_dup * M * cout_p by 2^31; a 64-bit division costs ~100 instructions)
+          const unsigned r0 = (unsigned)mc[k] / (unsigned)p.m_per_tb, r1 = (unsigned)(p.dup_rows + mc[k]) / (unsigned)p.m_per_tb;
+          b0[k] = *reinterpret_cast<const f32x4 *>(p.tbc + (size_t)r0 * p.tb_stride + cls[k] * p.cout_p + nn);
+          b1[k] = *reinterpret_cast<const f32x4 *>(p.tbc + (size_t)r1 * p.tb_stride + cls[k] * p.cout_p + nn);
         }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          f32x4 o0 = (v[k] + b0[k]) * sc + sh, o1 = (v[k] + b1[k]) * sc + sh;
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = fmaxf(o0[e], 0.f); o1[e] = fmaxf(o1[e], 0.f); }
+          }
+          o0 += rs[k]; o1 += rs[k];
+          if (ok[k] && !p.skip_out) {
+            *reinterpret_cast<f32x4 *>(p.out + (size_t)mrow[k] * p.cout_p + n) = o0;
+            *reinterpret_cast<f32x4 *>(p.out + ((size_t)p.dup_rows + mrow[k]) * p.cout_p + n) = o1;
+          }
+          *reinterpret_cast<f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4) = o0;
+          *reinterpret_cast<f32x4 *>(stage2 + (row0 + k * (256 / C4)) * P + c4 * 4) = o1;
+        }
+        pool_pass(mi, p.pool_out, stage, 2, WK * COPY, (size_t)(p.dup_rows >> 2) * p.cout_p);
+        continue;
       }
       for (int pass = 0; pass < p.n_dup; ++pass) {
         f32x4 o[U];
@@ -184,7 +224,8 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
           o[k] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (ok[k]) {
             const size_t mg = (size_t)pass * p.dup_rows + mrow[k];
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(p.tbc + (mg / p.m_per_tb) * p.tb_stride + cls[k] * p.cout_p + n);
+            const unsigned tr = (unsigned)(pass * p.dup_rows + mrow[k]) / (unsigned)p.m_per_tb;
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(p.tbc + (size_t)tr * p.tb_stride + cls[k] * p.cout_p + n);
             o[k] = (v[k] + b) * sc + sh;
             if (p.relu) {
 #pragma unroll
@@ -198,7 +239,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
           if (pass) __syncthreads();                   // the previous pass's windows are read
 #pragma unroll
           for (int k = 0; k < U; ++k) *reinterpret_cast<f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4) = o[k];
-          pool_pass(mi, p.pool_out + (size_t)pass * (p.dup_rows >> 2) * p.cout_p);
+          pool_pass(mi, p.pool_out + (size_t)pass * (p.dup_rows >> 2) * p.cout_p, stage, 1, 0, 0);
         }
       }
       continue;
@@ -281,7 +322,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
     if (p.pool_out) {
 #pragma unroll
       for (int k = 0; k < U; ++k) *reinterpret_cast<f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4) = v[k];
-      pool_pass(mi, p.pool_out);
+      pool_pass(mi, p.pool_out, stage, 1, 0, 0);
     }
   }
 }

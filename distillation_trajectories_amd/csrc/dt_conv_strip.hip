@@ -478,7 +478,8 @@ bool strip_admissible(int W, int bm, int bn, int prec) {
   return strip_lds_bytes(W, bm, bn, strip_kc(prec, bm, bn)) <= (prec == 3 ? 65536u : 98304u);
 }
 
-int launch_conv_strip(const ConvParams &p, int bm, int bn, int prec, hipStream_t s) {
+int launch_conv_strip(const ConvParams &p_in, int bm, int bn, int prec, hipStream_t s) {
+  ConvParams p = p_in;
   const int kc = strip_kc(prec, bm, bn);
   if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || prec < 3 || prec > 5) return DT_E_ARG;
   if (prec == 5 && (bm > 128 || (bm == 128 && bn == 128))) return DT_E_ARG;
@@ -487,7 +488,17 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int prec, hipStream_t
   if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 (3) strip items per thread cover BM + 2(W+1) <= 256 (384) rows
   if (bm == 256 && bn != 64) return DT_E_ARG;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
-  const size_t lds = strip_lds_bytes(p.W, bm, bn, kc);
+  size_t lds = strip_lds_bytes(p.W, bm, bn, kc);
+  p.dup_stage2 = 0;
+  if (p.n_dup == 2 && p.pool_out) {   // a second epilogue stage behind the first (and its K-split copies), if it fits this launch's LDS class
+    const size_t rows1 = bm == 256 || kc == 4 || (prec == 5 && bm == 128) ? 128 : 64;         // WK * WM * 32
+    const size_t rows2 = bm == 256 ? 128 : (bm == 128 ? 64 : 32);                              // WM * 32
+    const size_t need = (rows1 + (prec == 5 ? rows2 : rows1)) * (bn + 4) * sizeof(float);
+    if (need <= (prec == 3 ? 65536u : 98304u)) {
+      p.dup_stage2 = 1;
+      if (need > lds) lds = need;
+    }
+  }
   if (p.ablate && p.ablate != 7 && p.ablate != 8 && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
     switch (p.ablate) {
       case 1: conv_strip_bf16x6_kernel<128, 128, 1><<<grid, 256, lds, s>>>(p); break;

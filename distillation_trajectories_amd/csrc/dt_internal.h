@@ -119,6 +119,7 @@ struct ConvParams {
   const float *tbc;
   int n_dup, dup_rows;
   int skip_out;        // n_dup mode: do not store `out` (enc1's full-resolution output has no reader but the pool)
+  int dup_stage2;      // n_dup == 2: the launch's LDS holds a second epilogue stage (set by the strip launcher)
   int ablate;          // timing experiments only (wrong results): 1 no barrier, 2 no LDS reads, 3 no MFMA, 4 no staging
 };
 

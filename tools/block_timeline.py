@@ -27,9 +27,9 @@ LAYERS = [(0, 2, "enc1.conv2", 16, d[0]), (1, 1, "enc2.conv1", 8, d[1]), (1, 2, 
           (3, 1, "enc4.conv1", 2, d[3]), (6, 1, "dec2.conv1", 4, d[1]), (7, 1, "dec1.conv1", 8, d[0]), (7, 2, "dec1.conv2", 8, d[0])]
 print(f"sf={sf} batch_total={Bt}; per workgroup, microseconds (100 MHz wall clock): median [min .. max]")
 for j, slot, name, hw, cout in LAYERS:
-    M = Bt * hw * hw
+    M = (Bt // 2 if j == 0 else Bt) * hw * hw      # enc1.conv2 covers the B images once for both CFG passes
     npad = (cout + 63) // 64 * 64
-    for bm, bn in ((128, 128), (64, 64)):
+    for bm, bn in ((256, 64), (128, 128), (64, 64)):
         if npad % bn:
             continue
         grid = (M + bm - 1) // bm * (npad // bn)
