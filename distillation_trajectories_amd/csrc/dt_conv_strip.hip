@@ -198,13 +198,35 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     }
   };
 
+  // ---- K-split kernels: weight fragments straight from global memory.  With the step's chunks split across the waves a
+  // weight tile is multiplied by ONE wave (64 x 64 tile) or two (128 x 64, 64 x 128): staging it through LDS shares nothing
+  // and costs a barrier per tap.  The packed tile in global memory IS the LDS image (half-swap swizzle included), so a lane's
+  // B fragment is one 16-byte load; the fragments of step s + 1 are requested before the MFMAs of step s, and the only
+  // barriers left are the two around a strip restage.
+  constexpr bool DB = WK > 1 && ABL == 0;
+  bf16x8 fbn[KW][NI][3];
+  auto load_bd = [&](int adv) __attribute__((always_inline)) {
+    if (adv == ADV_TAP) wrun += tap_stride;
+    else if (adv == ADV_GROUP) wrun = wrun - 8 * tap_stride + group_stride;
+    else if (adv == ADV_SKIP0) wrun = wbase2;
+    else if (adv == ADV_SKIP) wrun += group_stride;
+    const __bf16 *wt = wrun - (bt * 8 + bsub * w_plane);           // the tile's first element (wrun carries this thread's staging offset)
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fbn[kw][ni][pl] = *reinterpret_cast<const bf16x8 *>(wt + ((wk * KW + kw) * 3 + pl) * w_plane + b_frag[ni]);
+  };
+
   const long long tl0 = p.ablate == 8 ? wall_clock64() : 0;      // timeline diagnostic (tools/block_timeline.py)
   // ---- prologue: strip of chunk 0, weights of step 0, the zero row
   load_strip(0);
-  load_b(ADV_NONE);
+  if (DB) load_bd(ADV_NONE); else load_b(ADV_NONE);
   if (tid < 48 * KC) *reinterpret_cast<u32x4 *>(As + (tid >> 4) * PLANE_A + RZ * 16 + (tid & 15) * 8) = u32x4{0u, 0u, 0u, 0u};
   write_strip();
-  write_b(0);
+  if (!DB) write_b(0);
   __syncthreads();
 
   // ABL == 9 (diagnostic build, tools/tap_phases.py): s_memtime stamps split every step into
@@ -231,7 +253,16 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     constexpr int tt = decltype(TT)::value;
     const bool more = !last_tap || next_chunk;
     if (first_tap && next_chunk && stage_next_strip && ABL != 5) load_strip(ch + 1);   // lands while this chunk's taps run
-    if (more && ABL != 2) load_b(adv);
+    bf16x8 fbc[KW][NI][3];                                         // DB: this step's weight fragments (requested during the previous step)
+    if (DB) {
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fbc[kw][ni][pl] = fbn[kw][ni][pl];
+      if (more) load_bd(adv);
+    } else if (more && ABL != 2) load_b(adv);
     {
       int wv = p.W;
       asm volatile("" : "+s"(wv));           // likewise: do not keep nine precomputed shifts in SGPRs
@@ -259,7 +290,8 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            fb[ni][pl] = (ABL == 4) ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
+            fb[ni][pl] = DB ? fbc[kw][ni][pl]
+                            : ((ABL == 4) ? __builtin_bit_cast(bf16x8, fake) : *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]));
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           bf16x8 fa[3];
@@ -287,13 +319,14 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     }
     stamp(0);
     if (ABL == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(1); }
-    if (more && ABL != 2) write_b((step + 1) & 1);
+    if (!DB && more && ABL != 2) write_b((step + 1) & 1);
     stamp(2);
-    if (last_tap && next_chunk && stage_next_strip && ABL != 5) {
+    const bool restage = last_tap && next_chunk && stage_next_strip && ABL != 5;
+    if (restage) {
       __syncthreads();                                             // every wave is done with this chunk's strip
       write_strip();
     }
-    if (ABL != 1 || last_tap) __syncthreads();
+    if (DB ? restage : (ABL != 1 || last_tap)) __syncthreads();
     stamp(3);
     ++step;
   };
@@ -325,7 +358,16 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   };
   auto skip_step = [&](f32x4 (&g)[KW][MI][2], int s2) __attribute__((always_inline)) {
     const bool more = s2 + 1 < n_skip;
-    if (more) load_b(ADV_SKIP);
+    bf16x8 fbc[KW][NI][3];
+    if (DB) {
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) fbc[kw][ni][pl] = fbn[kw][ni][pl];
+      if (more) load_bd(ADV_SKIP);
+    } else if (more) load_b(ADV_SKIP);
 #pragma unroll
     for (int kw = 0; kw < KW; ++kw) {
       const int kk = wk * KW + kw;
@@ -334,7 +376,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fb[ni][pl] = *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
+        for (int pl = 0; pl < 3; ++pl) fb[ni][pl] = DB ? fbc[kw][ni][pl] : *reinterpret_cast<const bf16x8 *>(B + pl * PLANE_B + b_frag[ni]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         bf16x8 fa[3];
@@ -353,8 +395,10 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
       }
     }
     if (s2 + 2 < n_skip) load_a(g, s2 + 2);
-    if (more) write_b((step + 1) & 1);
-    __syncthreads();
+    if (!DB) {
+      if (more) write_b((step + 1) & 1);
+      __syncthreads();
+    }
     ++step;
   };
 
@@ -397,7 +441,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
         float *red = reinterpret_cast<float *>(strip_lds);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          if (mi) __syncthreads();
+          if (mi || DB) __syncthreads();                             // (DB: the last step ended without a barrier; the strip is still being read)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -417,7 +461,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
         }
         if (wk == 0) conv_midpoint<MI, NI>(p, acc, n0, wn, l31);
         __syncthreads();
-        load_b(ADV_SKIP0);
+        if (DB) load_bd(ADV_SKIP0); else load_b(ADV_SKIP0);
         if (DIRECT) {
           load_a(ga0, 0);
           if (n_skip > 1) load_a(ga1, 1);
@@ -426,7 +470,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
           if (tid < 48 * KC) *reinterpret_cast<u32x4 *>(As + (tid >> 4) * PLANE_A + RZ * 16 + (tid & 15) * 8) = u32x4{0u, 0u, 0u, 0u};
           write_strip();
         }
-        write_b(step & 1);
+        if (!DB) write_b(step & 1);
         __syncthreads();
       }
     }
@@ -462,11 +506,13 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
 // 64 x 64 tile, 2 waves x 1 chunk on the 128 x 64 and 64 x 128 tiles
 int strip_kc(int prec, int bm, int bn) { return prec == 5 ? (bm == 64 && bn == 64 ? 4 : 2) : (prec == 4 ? 2 : 1); }
 
-static size_t strip_lds_bytes(int W, int bm, int bn, int kc) {
+static size_t strip_lds_bytes(int W, int bm, int bn, int prec) {
+  const int kc = strip_kc(prec, bm, bn);
   const int R = bm + 2 * strip_halo(W, bm);
-  const size_t loop = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 8) * 16 + (size_t)2 * 3 * bn * 16) * sizeof(__bf16);
-  // the staged epilogue reuses the same LDS: WM * 32 rows per copy, one copy per K-split wave (128 rows in every layout)
-  const size_t stage = (size_t)(bm == 256 || kc == 4 || (kc == 2 && bm == 128 && bn == 64) ? 128 : 64) * (bn + 4) * sizeof(float);   // (64 x 128 K-split: 2 x 32 rows)
+  // the strip's three planes per chunk; the double-buffered weight tile unless the waves take their fragments from global memory (K split)
+  const size_t loop = (size_t)kc * ((size_t)3 * (((R + 7) & ~7) + 8) * 16 + (prec == 5 ? 0 : (size_t)2 * 3 * bn * 16)) * sizeof(__bf16);
+  // the staged epilogue reuses the same LDS: WM * 32 rows per copy, one copy per K-split wave (128 rows in every K-split layout but 64 x 128)
+  const size_t stage = (size_t)(bm == 256 || (prec == 5 && bn == 64) ? 128 : 64) * (bn + 4) * sizeof(float);
   return loop > stage ? loop : stage;
 }
 
@@ -475,7 +521,7 @@ bool strip_admissible(int W, int bm, int bn, int prec) {
   if (bm == 256 && (bn != 64 || prec == 5)) return false;          // the 4 x 1 wave layout exists for 64-column tiles only
   if (prec == 5 && (bm > 128 || (bm == 128 && bn == 128))) return false;
   if (strip_kc(prec, bm, bn) == 4 && W + 1 > 32) return false;     // one strip item per thread: BM + 2(W+1) <= 128 rows
-  return strip_lds_bytes(W, bm, bn, strip_kc(prec, bm, bn)) <= (prec == 3 ? 65536u : 98304u);
+  return strip_lds_bytes(W, bm, bn, prec) <= (prec == 3 ? 65536u : 98304u);
 }
 
 int launch_conv_strip(const ConvParams &p_in, int bm, int bn, int prec, hipStream_t s) {
@@ -488,7 +534,7 @@ int launch_conv_strip(const ConvParams &p_in, int bm, int bn, int prec, hipStrea
   if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 (3) strip items per thread cover BM + 2(W+1) <= 256 (384) rows
   if (bm == 256 && bn != 64) return DT_E_ARG;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
-  size_t lds = strip_lds_bytes(p.W, bm, bn, kc);
+  size_t lds = strip_lds_bytes(p.W, bm, bn, prec);
   p.dup_stage2 = 0;
   if (p.n_dup == 2 && p.pool_out) {   // a second epilogue stage behind the first (and its K-split copies), if it fits this launch's LDS class
     const size_t rows1 = bm == 256 || kc == 4 || (prec == 5 && bm == 128) ? 128 : 64;         // WK * WM * 32
