@@ -86,9 +86,25 @@ def generate_trajectory(model, noise, timesteps, device, seed=None, guidance_sca
 
 # ------------------------------------------------------------------------------------ batched grid
 _TEACHER_CACHE = {}
+_ROW_CONSTS = {}
 
 
-def sample_grid_groups(handle, table, first_row, num_samples, timesteps, guidance_scales, H, W):
+def _grid_rows(device, S, G, first_row, group, cfg):
+    """(z_row int32 [G*S], w float32 [G*S] or None) on ``device`` for one CFG plan, uploaded once per distinct plan: a
+    pageable host-to-device copy blocks the host until the stream has drained, so per-call uploads would keep a worker from
+    queueing the next sampler loop behind the running one."""
+    key = (str(device), S, G, first_row, tuple(group), cfg)
+    hit = _ROW_CONSTS.get(key)
+    if hit is None:
+        if len(_ROW_CONSTS) > 64:
+            _ROW_CONSTS.clear()
+        z_row = (torch.arange(S, dtype=torch.int32).repeat(G) + first_row).to(device)
+        w = torch.tensor([float(gs) for gs in group], dtype=torch.float32).repeat_interleave(S).to(device) if cfg else None
+        hit = _ROW_CONSTS[key] = (z_row, w)
+    return hit
+
+
+def sample_grid_groups(handle, table, first_row, num_samples, timesteps, guidance_scales, H, W, throttle=False):
     """Trajectories of one model, one launch sequence per CFG plan: [(scales, traj [T+1, G*S, E])].
 
     ``table`` is the device noise table [rows, E]; sample s starts from row first_row+s and takes
@@ -96,6 +112,11 @@ def sample_grid_groups(handle, table, first_row, num_samples, timesteps, guidanc
     with batch = S x (#scales) and a per-row guidance scale; the scales that do not take the reference's
     two-pass branch (gs <= 1, None) all give the same trajectory, so that group has G = 1.
     Rows [g*S, (g+1)*S) of a group's tensor belong to its g-th scale.
+
+    ``throttle``: return only once every group but the last has finished on the device (the host waits on an event
+    recorded between the groups).  The grid's worker threads use it so that a thread holds at most two sampler loops in
+    its stream when it picks its next model: models are then handed out by GPU progress (dynamic load balance across the
+    streams) instead of by how fast the host can queue launches.
     """
     S, T = num_samples, timesteps
     E = table.shape[1]
@@ -103,22 +124,25 @@ def sample_grid_groups(handle, table, first_row, num_samples, timesteps, guidanc
     order = list(range(T - 1, -1, -1))
     plain = [gs for gs in guidance_scales if not uses_cfg(gs)]
     guided = [gs for gs in guidance_scales if uses_cfg(gs)]
-    groups = []
+    groups, marks = [], []
     for cfg, group in ((False, plain), (True, guided)):
         if not group:
             continue
         G = len(group) if cfg else 1            # without CFG every scale gives the same trajectory
-        z_row = (torch.arange(S, dtype=torch.int32).repeat(G) + first_row).to(table.device, non_blocking=True)
+        z_row, w = _grid_rows(table.device, S, G, first_row, group, cfg)
         traj = torch.empty(T + 1, G * S, E, dtype=torch.float32, device=table.device)
         traj[0].copy_(table[first_row: first_row + S].repeat(G, 1))
-        w = None
-        if cfg:
-            w = torch.tensor([float(gs) for gs in group], dtype=torch.float32).repeat_interleave(S).to(table.device, non_blocking=True)
         t_rows, modes, n_pass = _plan(T, cfg)
         tb = handle.time_bias(t_rows, modes)
         handle.sample(RULE_ENGINE, traj, H, W, tb, n_pass, [coefs[t] for t in order], [t > 0 for t in order],
                       z=table, z_row=z_row, z_shift=list(order), w=w)
         groups.append((list(group), traj))
+        if throttle:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(table.device))
+            marks.append(ev)
+    for ev in marks[:-1]:
+        ev.synchronize()
     return groups
 
 

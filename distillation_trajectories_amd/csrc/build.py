@@ -40,22 +40,36 @@ def is_stale():
     return _newer(LIB, deps)
 
 
-def build(force=False, verbose=False):
+TOOLS_MARK = os.path.join(OBJ_DIR, "tools_build")
+
+
+def build(force=False, verbose=False, tools=False):
     """Compile every HIP source for gfx950 (one object per source, in parallel, only what changed unless
-    ``force``) and link the shared library.  Returns its path."""
+    ``force``) and link the shared library.  Returns its path.
+
+    ``tools=True`` (``--tools``) defines DT_TOOLS: the ablation instantiations of the convolution kernels and the
+    DT_ABLATE switch of dt_unet_time_conv (timing experiments that produce WRONG results by design, tools/ablate.py,
+    tools/tap_phases.py, tools/block_timeline.py).  The default library contains none of that; switching between the
+    two kinds rebuilds everything."""
+    if bool(tools) != os.path.exists(TOOLS_MARK):
+        force = True
     if not force and not is_stale():
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = hipcc_path()
     common = [os.path.join(HERE, f) for f in HEADERS] + [os.path.abspath(__file__)]
+    if tools:
+        open(TOOLS_MARK, "w").close()
+    elif os.path.exists(TOOLS_MARK):
+        os.remove(TOOLS_MARK)
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         path = os.path.join(HERE, src)
         if not force and not _newer(obj, [path] + common):
             return obj, None
-        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + (["-DDT_TOOLS"] if tools else []) + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         return obj, subprocess.run(cmd, capture_output=True, text=True)
@@ -81,4 +95,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tools="--tools" in sys.argv))

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM * BN > 128 * 128 ? 2 : 3) void con
 
 int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s) {
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
+#ifdef DT_TOOLS   // ablation instantiations (wrong results by design) exist only in a tools build (build.py --tools)
   if (p.ablate && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
     switch (p.ablate) {
       case 1: conv_gemm_bf16x6_kernel<128, 128, 1><<<grid, 256, 0, s>>>(p); break;
@@ -208,6 +209,7 @@ int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s) {
     DT_LAUNCH_CHECK();
     return DT_OK;
   }
+#endif
   if (bm == 128 && bn == 128) conv_gemm_bf16x6_kernel<128, 128><<<grid, 256, 0, s>>>(p);
   else if (bm == 128) conv_gemm_bf16x6_kernel<128, 64><<<grid, 256, 0, s>>>(p);
   else if (bn == 128) conv_gemm_bf16x6_kernel<64, 128><<<grid, 256, 0, s>>>(p);

@@ -545,6 +545,7 @@ int launch_conv_strip(const ConvParams &p_in, int bm, int bn, int prec, hipStrea
       if (need > lds) lds = need;
     }
   }
+#ifdef DT_TOOLS   // ablation instantiations (wrong results by design) exist only in a tools build (build.py --tools)
   if (p.ablate && p.ablate != 7 && p.ablate != 8 && bm == 128 && bn == 128) {     // timing experiments (tools/ablate.py)
     switch (p.ablate) {
       case 1: conv_strip_bf16x6_kernel<128, 128, 1><<<grid, 256, lds, s>>>(p); break;
@@ -559,6 +560,7 @@ int launch_conv_strip(const ConvParams &p_in, int bm, int bn, int prec, hipStrea
     DT_LAUNCH_CHECK();
     return DT_OK;
   }
+#endif
   if (prec >= 4) {
     static std::once_flag attr_once;   // 128x128 needs 80 KB of dynamic LDS; launches come from several host threads
     static int attr_status = DT_OK;

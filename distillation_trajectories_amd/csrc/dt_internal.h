@@ -34,6 +34,7 @@ struct ProfileScope {
   ~ProfileScope();
   int slot;
   hipStream_t stream;
+  void *end_event;
 };
 
 // bilinear source coordinates for scale factor 2 with align_corners=True (ATen area_pixel_compute_scale:

@@ -64,27 +64,24 @@ const char *kClassName[KC_COUNT] = {
 }  // namespace
 
 namespace dt {
-ProfileScope::ProfileScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+ProfileScope::ProfileScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s), end_event(nullptr) {
   if (!g_prof.on.load(std::memory_order_relaxed)) return;
   hipEvent_t a;
   {
     std::lock_guard<std::mutex> lock(g_prof.mu);
+    if (!g_prof.on.load(std::memory_order_relaxed)) return;   // a concurrent dt_profile_end
     a = g_prof.get();
     hipEvent_t b = g_prof.get();
     if (!a || !b) return;
     g_prof.rec.push_back(ProfRecord{a, b, cls, flops, bytes});
     slot = (int)g_prof.rec.size() - 1;
+    end_event = b;             // kept here: a concurrent dt_profile_begin may clear `rec` before the destructor runs
   }
   (void)hipEventRecord(a, s);
 }
 ProfileScope::~ProfileScope() {
   if (slot < 0) return;
-  hipEvent_t b;
-  {
-    std::lock_guard<std::mutex> lock(g_prof.mu);
-    b = g_prof.rec[slot].b;
-  }
-  (void)hipEventRecord(b, stream);
+  (void)hipEventRecord((hipEvent_t)end_event, stream);
 }
 }  // namespace dt
 
@@ -683,7 +680,9 @@ int dt_unet_time_conv(const dt_unet *h, int batch_total, int H, int W, int block
   ConvParams p;
   if (!conv_slot(h, block, slot, in, ws, pl, batch_total, h->slab, batch_total, &c, p)) { *ms = 0.f; *flops = 0.0; return DT_OK; }
   *flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));
-  if (const char *ab = getenv("DT_ABLATE")) p.ablate = atoi(ab);   // timing experiments only
+#ifdef DT_TOOLS
+  if (const char *ab = getenv("DT_ABLATE")) p.ablate = atoi(ab);   // timing experiments only (tools build: build.py --tools)
+#endif
   hipEvent_t e0, e1;
   DT_HIP_TRY(hipEventCreate(&e0));
   DT_HIP_TRY(hipEventCreate(&e1));
@@ -823,7 +822,7 @@ int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, i
                          const float *coef, const int32_t *has_noise, const float *z, const int32_t *z_row,
                          const int64_t *z_shift, const float *w, float w_scalar, float *traj, float *eps_scratch,
                          void *ws, size_t ws_bytes, void *stream) {
-  if (!h || !tb || !coef || !has_noise || !traj || !eps_scratch || !ws) return DT_E_NULL;
+  if (!h || !tb || !coef || !has_noise || !traj || !ws) return DT_E_NULL;   // (eps_scratch is unused since the fused update: NULL is fine)
   if (n_pass < 1 || n_pass > 2 || n_steps < 0 || rule < 0 || rule > DT_RULE_MANAGER) return DT_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   const char *genv = getenv("DT_GRAPH");
@@ -875,6 +874,7 @@ int dt_profile_marker(int id, void *stream) {
 }
 
 int dt_profile_begin(void) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   g_prof.rec.clear();
   g_prof.used = 0;
   g_prof.on = true;
@@ -882,6 +882,7 @@ int dt_profile_begin(void) {
 }
 
 int dt_profile_end(void) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   g_prof.on = false;
   return DT_OK;
 }
@@ -892,6 +893,7 @@ int dt_profile_read(int cls, const char **name, long long *launches, double *ms,
   if (cls < 0 || cls >= KC_COUNT || !launches || !ms || !flops || !bytes) return DT_E_ARG;
   if (name) *name = kClassName[cls];
   *launches = 0; *ms = 0; *flops = 0; *bytes = 0;
+  std::lock_guard<std::mutex> lock(g_prof.mu);
   for (const ProfRecord &r : g_prof.rec) {
     if (r.cls != cls) continue;
     DT_HIP_TRY(hipEventSynchronize(r.b));

@@ -103,6 +103,7 @@ class UNetHandle:
         mode = os.environ.get("DT_PRECISION", "auto")
         check(self.lib.dt_unet_set_precision(self.h, {"fp32": 0, "split-bf16": 1, "auto": 2}[mode]), "dt_unet_set_precision")
         self._ws = {}
+        self._consts = {}
         self._tuned = set()
 
     def __del__(self):
@@ -138,7 +139,9 @@ class UNetHandle:
 
     # ------------------------------------------------------------------ primitives
     def workspace(self, batch_total, H, W):
-        key = (batch_total, H, W)
+        """Scratch of one forward shape, one buffer PER STREAM: two streams may run the same handle concurrently
+        (activations live in the workspace, so a shared buffer would be a silent race)."""
+        key = (batch_total, H, W, torch.cuda.current_stream(self.device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None:
             n = self.lib.dt_unet_workspace_bytes(self.h, batch_total, H, W)
@@ -210,12 +213,22 @@ class UNetHandle:
         return out
 
     def time_bias(self, t_values, cond_modes):
-        """[rows, tb_stride] table for rows (t_values[i], cond_modes[i]); cond mode in {NONE, ZERO, ONE}."""
+        """[rows, tb_stride] table for rows (t_values[i], cond_modes[i]); cond mode in {NONE, ZERO, ONE}.
+
+        The three small index tensors are uploaded once per distinct row list and kept with the handle: a pageable
+        host-to-device copy blocks the host until the stream has drained, which would stop a caller from queueing one
+        sampler loop behind another."""
         rows = len(t_values)
-        t = torch.tensor(list(t_values), dtype=torch.int32).to(self.device)
-        cond = torch.tensor([1.0 if m == COND_ONE else 0.0 for m in cond_modes], dtype=torch.float32).to(self.device)
-        present = torch.tensor([0 if m == COND_NONE else 1 for m in cond_modes], dtype=torch.uint8).to(self.device)
-        return self.time_bias_general(t, cond, present, rows)
+        key = ("tb_in", tuple(int(v) for v in t_values), tuple(int(m) for m in cond_modes))
+        cached = self._consts.get(key)
+        if cached is None:
+            if len(self._consts) > 16:
+                self._consts.clear()
+            t = torch.tensor(list(t_values), dtype=torch.int32).to(self.device)
+            cond = torch.tensor([1.0 if m == COND_ONE else 0.0 for m in cond_modes], dtype=torch.float32).to(self.device)
+            present = torch.tensor([0 if m == COND_NONE else 1 for m in cond_modes], dtype=torch.uint8).to(self.device)
+            cached = self._consts[key] = (t, cond, present)
+        return self.time_bias_general(cached[0], cached[1], cached[2], rows)
 
     def time_bias_general(self, t_i32, cond_f32, present_u8, rows):
         out = torch.empty(rows, self.tb_stride, dtype=torch.float32, device=self.device)
@@ -271,19 +284,13 @@ class UNetHandle:
         coef_c = (c_float * (4 * n_steps))(*[float(v) for row in coef for v in (list(row) + [0.0] * 4)[:4]])
         noise_c = (c_int32 * n_steps)(*[int(bool(v)) for v in has_noise])
         shift_c = (c_int64 * n_steps)(*[int(v) for v in (z_shift if z_shift is not None else [0] * n_steps)])
-        # scratch for the predictions lives with the handle: stable addresses let the library replay its
-        # captured hipGraph of the loop on repeated calls
-        ekey = ("eps", n_pass, B, traj.shape[2])
-        eps = self._ws.get(ekey)
-        if eps is None:
-            eps = self._ws[ekey] = torch.empty(n_pass, B, traj.shape[2], dtype=torch.float32, device=self.device)
         ws = self.workspace(n_pass * B, H, W)
         if n_steps and self._wants_tuning(n_pass * B, H, W, None):
             self.forward(traj[0].reshape(B, self.channels, H, W), tb[:n_pass].contiguous(), n_pass, B, tune=True)
         with torch.cuda.device(self.device):
             check(self.lib.dt_sample_trajectory(self.h, rule, B, n_pass, H, W, n_steps, ptr(tb), coef_c, noise_c,
                                                 ptr(z), ptr(z_row), shift_c, ptr(w), c_float(w_scalar), ptr(traj),
-                                                ptr(eps), ptr(ws), c_size_t(ws.numel()), stream_ptr()),
+                                                None, ptr(ws), c_size_t(ws.numel()), stream_ptr()),
                   "dt_sample_trajectory")
         return traj
 

@@ -47,6 +47,17 @@ def all_gather_rows(local, counts, dim):
     return torch.cat([p.narrow(dim, 0, c) for p, c in zip(parts, counts)], dim=dim)
 
 
+_STREAMS = {}
+
+
+def _side_streams(device, n):
+    """n HIP streams of ``device``, created once (workspaces are cached per (handle, shape, stream))."""
+    have = _STREAMS.setdefault(str(device), [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
 def _upload(host):
     """Host tensor -> current device through pinned memory, asynchronously on the current stream."""
     return host.pin_memory().to(torch.device("cuda", torch.cuda.current_device()), non_blocking=True)
@@ -55,10 +66,10 @@ def _upload(host):
 def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, count, device, table=None, streams=None):
     """float64 tensor [n_sf, n_gs, count, K] on ``device`` for samples first_sample .. +count-1 (seed 42+s).
 
-    The teacher runs once per CFG plan on the current stream.  The students are independent of each other and of
-    the teacher until the metric reductions, so they are spread over ``streams`` side streams (default
-    DT_GRID_STREAMS or 3), one host thread each: the small students, whose launches cannot fill 256 CUs, overlap
-    the big ones.  Every device result stays in HBM until ONE device-to-host copy at the end; the scalar
+    The teacher runs once per CFG plan on the current stream, alone (see the note at its launch).  The students are
+    independent of each other, so they then share the chip on ``streams`` side streams (default DT_GRID_STREAMS or 3),
+    one host thread each, largest model first, the next model handed to whichever thread's stream has drained furthest:
+    the small students, whose launches cannot fill 256 CUs, overlap the bigger ones.  Every device result stays in HBM until ONE device-to-host copy at the end; the scalar
     post-transforms then run once, vectorised over every (student, scale, sample) row.
     ``table``: the device noise table [count+T-1, E] when the caller already holds it (bench.py).
     """
@@ -88,21 +99,23 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
                     x = table[torch.arange(B, device=device) % table.shape[0]]        # real noise: zeros clock differently
                     h.forward(x.reshape(B, C, H, H), tb, n_pass, B, tune=True)
         main = torch.cuda.current_stream()
-        t_groups = sample_grid_groups(handles[0], table, 0, count, T, scales, H, H)
-        teacher_done = torch.cuda.Event()
-        teacher_done.record(main)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        row_sets = []
-        for group, X in t_groups:
-            G = X.shape[1] // count
-            row_sets.append(None if index_row is None else index_row.repeat(G).to(device, non_blocking=True))
+        from .analysis.trajectory_engine import uses_cfg
+        n_guided = sum(1 for gs in scales if uses_cfg(gs))
+        group_sizes = ([1] if n_guided < len(scales) else []) + ([n_guided] if n_guided else [])   # G of the plain / guided plan
+        row_sets = [None if index_row is None else index_row.repeat(G).to(device) for G in group_sizes]
         n_streams = max(1, min(len(students), streams or int(os.environ.get("DT_GRID_STREAMS", "3"))))
-        side = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        side = _side_streams(device, n_streams)          # kept across calls: a handle keeps one workspace per stream
         results = [None] * len(students)
         errors = []
         order = sorted(range(len(students)), key=lambda i: -sum(p.numel() for p in students[i].parameters()))
         lock = threading.Lock()
+        # The teacher runs FIRST, alone: measured on MI355X (configs[2], same box, alternating runs) its loop sharing the
+        # chip with the students' small launches costs 13 % of the step (469-482 vs 418-428 ms) -- its big tiles are tuned
+        # for an idle chip and lose more to the interference than the students gain from the overlap.  The students then
+        # share the chip among themselves on the side streams.
+        t_groups = sample_grid_groups(handles[0], table, 0, count, T, scales, H, H)
+        ready = torch.cuda.Event()       # the teacher's trajectories (and every upload above) are complete
+        ready.record(main)
 
         def worker(k):
             try:
@@ -113,8 +126,7 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
                             if not order:
                                 return
                             i = order.pop(0)
-                        s_groups = sample_grid_groups(handles[1 + i], table, 0, count, T, scales, H, H)
-                        side[k].wait_event(teacher_done)
+                        s_groups = sample_grid_groups(handles[1 + i], table, 0, count, T, scales, H, H, throttle=len(side) > 1)
                         parts = []
                         for (_, X), (_, Y), rows in zip(t_groups, s_groups, row_sets):
                             sums = engine.device_metric_sums(X, Y)                       # [G*S, n, 4]
@@ -123,7 +135,12 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
                         results[i] = torch.cat(parts, dim=0)
             except Exception as e:       # surfaced on the calling thread
                 errors.append(e)
-        threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_streams)]
+        if streams == 1:                 # serial mode (per-kernel profiling): everything on the caller's stream, in order
+            side = [main]
+            worker(0)
+            threads = []
+        else:
+            threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_streams)]
         for t in threads:
             t.start()
         for t in threads:
@@ -131,7 +148,8 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
         if errors:
             raise errors[0]
         for st in side:
-            main.wait_stream(st)
+            if st is not main:
+                main.wait_stream(st)
         host = torch.stack(results).cpu().numpy()                   # the one D2H: [n_sf, rows, 5n] float64
     n_sf, n_rows = host.shape[0], host.shape[1]
     flat = host.reshape(n_sf * n_rows, 5 * n)
