@@ -12,7 +12,7 @@ COND_NONE, COND_ZERO, COND_ONE = 0, 1, 2
 RULE_ENGINE, RULE_PSAMPLE, RULE_MANAGER = 0, 1, 2
 PREC_FP32, PREC_SPLIT_BF16, PREC_AUTO = 0, 1, 2
 BT_COUNT, GT_COUNT, N_BLOCKS = 16, 9, 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipLibraryError(RuntimeError):
@@ -49,6 +49,11 @@ SIGNATURES = {
     "dt_sample_trajectory": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, POINTER(c_float),
                                      POINTER(c_int32), c_void_p, c_void_p, POINTER(c_int64), c_void_p, c_float,
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dt_unet_forward_mixed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
+    "dt_sample_trajectory_mixed": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                           POINTER(c_float), POINTER(c_int32), c_void_p, c_void_p, POINTER(c_int64),
+                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dt_traj_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dt_traj_wasserstein": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                     c_void_p]),

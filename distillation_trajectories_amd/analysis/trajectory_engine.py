@@ -104,19 +104,38 @@ def _grid_rows(device, S, G, first_row, group, cfg):
     return hit
 
 
+class GridGroup(tuple):
+    """(scales, traj, block_of): one launch sequence of ``sample_grid_groups``.  ``traj`` is [T+1, n_blocks*S, E];
+    rows [b*S, (b+1)*S) hold the S samples of row block b, and scales[i] lives in block block_of[i]."""
+    __slots__ = ()
+
+    def __new__(cls, scales, traj, block_of):
+        return tuple.__new__(cls, (list(scales), traj, list(block_of)))
+
+    scales = property(lambda self: self[0])
+    traj = property(lambda self: self[1])
+    block_of = property(lambda self: self[2])
+
+
+def _merge_plans():
+    import os
+    return os.environ.get("DT_GRID_MERGE", "1") != "0"
+
+
 def sample_grid_groups(handle, table, first_row, num_samples, timesteps, guidance_scales, H, W, throttle=False):
-    """Trajectories of one model, one launch sequence per CFG plan: [(scales, traj [T+1, G*S, E])].
+    """Trajectories of one model for every guidance scale: a list of ``GridGroup`` (one per launch sequence).
 
     ``table`` is the device noise table [rows, E]; sample s starts from row first_row+s and takes
-    row first_row+s+t at timestep t.  All guidance scales of one CFG plan share one launch sequence
-    with batch = S x (#scales) and a per-row guidance scale; the scales that do not take the reference's
-    two-pass branch (gs <= 1, None) all give the same trajectory, so that group has G = 1.
-    Rows [g*S, (g+1)*S) of a group's tensor belong to its g-th scale.
+    row first_row+s+t at timestep t.  The scales that do not take the reference's two-pass branch (gs <= 1, None:
+    trajectory_engine.py:65,83) all give the same trajectory and share ONE row block; every CFG scale has a row block
+    of its own with a per-row guidance scale.  When both kinds are present they run as ONE mixed launch sequence
+    (dt_sample_trajectory_mixed: the single-pass samples ride in the CFG samples' launches -- block 0 single-pass,
+    blocks 1..G the CFG scales); DT_GRID_MERGE=0 keeps one sequence per kind (two GridGroups).
 
-    ``throttle``: return only once every group but the last has finished on the device (the host waits on an event
-    recorded between the groups).  The grid's worker threads use it so that a thread holds at most two sampler loops in
-    its stream when it picks its next model: models are then handed out by GPU progress (dynamic load balance across the
-    streams) instead of by how fast the host can queue launches.
+    ``throttle``: return only once every launch sequence but the last has finished on the device (the host waits on
+    an event recorded between them).  The grid's worker threads use it so that a thread holds at most two sampler
+    loops in its stream when it picks its next model: models are then handed out by GPU progress (dynamic load
+    balance across the streams) instead of by how fast the host can queue launches.
     """
     S, T = num_samples, timesteps
     E = table.shape[1]
@@ -124,22 +143,41 @@ def sample_grid_groups(handle, table, first_row, num_samples, timesteps, guidanc
     order = list(range(T - 1, -1, -1))
     plain = [gs for gs in guidance_scales if not uses_cfg(gs)]
     guided = [gs for gs in guidance_scales if uses_cfg(gs)]
+    dev = table.device
     groups, marks = [], []
+    if plain and guided and _merge_plans():
+        G = len(guided)
+        key = (str(dev), "mixed", S, first_row, tuple(guided))
+        hit = _ROW_CONSTS.get(key)
+        if hit is None:
+            z_row = (torch.arange(S, dtype=torch.int32).repeat(1 + G) + first_row).to(dev)
+            w = torch.cat([torch.zeros(S), torch.tensor([float(gs) for gs in guided], dtype=torch.float32).repeat_interleave(S)]).to(dev)
+            hit = _ROW_CONSTS[key] = (z_row, w)
+        z_row, w = hit
+        traj = torch.empty(T + 1, (1 + G) * S, E, dtype=torch.float32, device=dev)
+        traj[0].copy_(table[first_row: first_row + S].repeat(1 + G, 1))
+        # time-bias rows of a step, one per S rows of the forward: [cond None | cond 0 x G | cond 1 x G]
+        modes = ([COND_NONE] + [COND_ZERO] * G + [COND_ONE] * G) * T
+        t_rows = [t for t in order for _ in range(1 + 2 * G)]
+        tb = handle.time_bias(t_rows, modes)
+        handle.sample_mixed(RULE_ENGINE, traj, H, W, tb, S, S, [coefs[t] for t in order], [t > 0 for t in order],
+                            z=table, z_row=z_row, z_shift=list(order), w=w)
+        return [GridGroup(plain + guided, traj, [0] * len(plain) + list(range(1, 1 + G)))]
     for cfg, group in ((False, plain), (True, guided)):
         if not group:
             continue
         G = len(group) if cfg else 1            # without CFG every scale gives the same trajectory
-        z_row, w = _grid_rows(table.device, S, G, first_row, group, cfg)
-        traj = torch.empty(T + 1, G * S, E, dtype=torch.float32, device=table.device)
+        z_row, w = _grid_rows(dev, S, G, first_row, group, cfg)
+        traj = torch.empty(T + 1, G * S, E, dtype=torch.float32, device=dev)
         traj[0].copy_(table[first_row: first_row + S].repeat(G, 1))
         t_rows, modes, n_pass = _plan(T, cfg)
         tb = handle.time_bias(t_rows, modes)
         handle.sample(RULE_ENGINE, traj, H, W, tb, n_pass, [coefs[t] for t in order], [t > 0 for t in order],
                       z=table, z_row=z_row, z_shift=list(order), w=w)
-        groups.append((list(group), traj))
+        groups.append(GridGroup(group, traj, list(range(G)) if cfg else [0] * len(group)))
         if throttle:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(table.device))
+            ev.record(torch.cuda.current_stream(dev))
             marks.append(ev)
     for ev in marks[:-1]:
         ev.synchronize()
@@ -147,13 +185,13 @@ def sample_grid_groups(handle, table, first_row, num_samples, timesteps, guidanc
 
 
 def sample_grid(handle, table, first_row, num_samples, timesteps, guidance_scales, H, W):
-    """{gs: device tensor view [T+1, S, E]} over ``sample_grid_groups``."""
+    """{gs: device tensor [T+1, S, E]} over ``sample_grid_groups`` (views of the groups' tensors: not contiguous when a
+    group holds several row blocks)."""
     S = num_samples
     out = {}
-    for group, traj in sample_grid_groups(handle, table, first_row, S, timesteps, guidance_scales, H, W):
-        for g, gs in enumerate(group):
-            lo = g * S if traj.shape[1] > S else 0           # the plain group holds one trajectory for all its scales
-            out[gs] = traj[:, lo: lo + S]
+    for scales, traj, block_of in sample_grid_groups(handle, table, first_row, S, timesteps, guidance_scales, H, W):
+        for gs, b in zip(scales, block_of):
+            out[gs] = traj[:, b * S: (b + 1) * S]
     return out
 
 

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 4) void conv_gemm_kernel(const ConvParams p) {
         const bool ok = a_ok[j] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
         ra[j] = ok ? *reinterpret_cast<const f32x4 *>(p.in + a_off[j] + shift) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const float *wt = wbase + (size_t)(tap * CC + cc) * p.n_p * 16;
+      const float *wt = wbase + (size_t)(tap * p.ccw + cc) * p.n_p * 16;
 #pragma unroll
       for (int j = 0; j < B_PER; ++j) rb[j] = *reinterpret_cast<const f32x4 *>(wt + j * 1024);
       if (++cc == CC) { cc = 0; ++tap; }
@@ -157,7 +157,8 @@ int launch_conv(const ConvParams &p, hipStream_t s) {
   const bool tall_m = bm == 128, wide_n = bn == 128;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);
   if (p.splits < 1 || (p.splits > 1 && !p.slab)) return DT_E_ARG;
-  if (p.prec >= 3 ? ((p.cin_p >> 4) % (p.splits * strip_kc(p.prec, bm, bn)) != 0) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % p.splits != 0)) return DT_E_ARG;
+  if (p.ccw < (p.cin_p >> 4) || (p.in2 && p.ccw2 < (p.cin2_p >> 4))) return DT_E_ARG;   // weight chunks per tap of the pack in use
+  if (p.prec >= 3 ? !chunks_fit(p.cin_p >> 4, p.ccw, p.splits * strip_kc(p.prec, bm, bn)) : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % p.splits != 0)) return DT_E_ARG;
   // algorithmic flops: what the reference's conv2d does on the unpadded shape (all ksize^2 taps)
   if (p.in2 && (p.splits != 1 || !p.w2 || !p.bias2 || p.cin2_p % 16)) return DT_E_ARG;
   const double flops = 2.0 * p.M * (double)p.cout_real * ((double)p.cin_real * p.ksize * p.ksize + (p.in2 ? p.cin2_real : 0));

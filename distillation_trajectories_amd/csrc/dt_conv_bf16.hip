@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * WM * WN, BM * BN > 128 * 128 ? 2 : 3) void con
           ra1[i] = *reinterpret_cast<const f32x4 *>(src + 4);
         }
       }
-      const __bf16 *wt = wbase + (size_t)(tap * CC + cc) * 3 * w_plane;
+      const __bf16 *wt = wbase + (size_t)(tap * p.ccw + cc) * 3 * w_plane;
 #pragma unroll
       for (int i = 0; i < BP; ++i)
         if (tid + i * NT < BN * 2) {
@@ -222,7 +222,7 @@ int launch_conv_bf16x6(const ConvParams &p, int bm, int bn, hipStream_t s) {
 // Weight split + re-tiling (once per model): wp is bf16 [K/16][3][n_p][16], element k = 8*hh + j of row n
 // stored at half (hh ^ ((n>>3)&1)); k = tap*cin_p + cp with the same concat mapping as pack_conv_kernel.
 __global__ void pack_conv_bf16x3_kernel(const float *__restrict__ w, __bf16 *__restrict__ wp, int cout, int cin,
-                                        int ksize, int cin_p, int n_p, int split_c, int split_cp, size_t total) {
+                                        int ksize, int cin_p, int cin_w, int n_p, int split_c, int split_cp, size_t total) {
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     // idx enumerates (kc, n, phys position 0..15); the three planes are written together
     const int pos = idx & 15;
@@ -232,10 +232,10 @@ __global__ void pack_conv_bf16x3_kernel(const float *__restrict__ w, __bf16 *__r
     const int phh = pos >> 3, j = pos & 7;
     const int hh = phh ^ ((n >> 3) & 1);
     const int k = (int)kc * 16 + hh * 8 + j;
-    const int tap = k / cin_p, cp = k - tap * cin_p;
+    const int tap = k / cin_w, cp = k - tap * cin_w;       // (channels [cin_p, cin_w) of a tap: zero chunks, see ConvParams::ccw)
     int c = -1;
     if (cp < split_cp) { if (cp < split_c) c = cp; }
-    else { const int cc = split_c + (cp - split_cp); if (cc < cin) c = cc; }
+    else if (cp < cin_p) { const int cc = split_c + (cp - split_cp); if (cc < cin) c = cc; }
     float v = 0.f;
     if (n < cout && c >= 0) v = w[((size_t)n * cin + c) * (ksize * ksize) + tap];
     const __bf16 a1 = (__bf16)v;
@@ -248,11 +248,12 @@ __global__ void pack_conv_bf16x3_kernel(const float *__restrict__ w, __bf16 *__r
   }
 }
 
-int launch_pack_conv_bf16x3(const float *w, void *wp, int cout, int cin, int ksize, int cin_p, int n_p, int split_c,
+int launch_pack_conv_bf16x3(const float *w, void *wp, int cout, int cin, int ksize, int cin_p, int cin_w, int n_p, int split_c,
                             int split_cp, hipStream_t s) {
-  const size_t total = (size_t)ksize * ksize * cin_p * n_p;
+  if (cin_w < cin_p || cin_w % 16) return DT_E_ARG;
+  const size_t total = (size_t)ksize * ksize * cin_w * n_p;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  pack_conv_bf16x3_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<__bf16 *>(wp), cout, cin, ksize, cin_p, n_p,
+  pack_conv_bf16x3_kernel<<<blocks, 256, 0, s>>>(w, reinterpret_cast<__bf16 *>(wp), cout, cin, ksize, cin_p, cin_w, n_p,
                                                  split_c, split_cp, total);
   DT_LAUNCH_CHECK();
   return DT_OK;

@@ -125,7 +125,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
       const int L0 = 2 * yy * p.W + 2 * xx;
       const int m = m0 + (pp >> 3) * (MI * 32) + mi * 32 + L0;
       const int qn = n0 + qc * 4;
-      if (m >= p.M || qn >= p.cout_p) continue;
+      if (m >= p.M || qn >= p.cout_p || (pass && m < p.dup_skip)) continue;
       const float *s0 = src + pass * src_pitch + ((pp >> 3) * 32 + L0) * P + qc * 4;
       const f32x4 a = *reinterpret_cast<const f32x4 *>(s0), b = *reinterpret_cast<const f32x4 *>(s0 + P);
       const f32x4 c = *reinterpret_cast<const f32x4 *>(s0 + p.W * P), d = *reinterpret_cast<const f32x4 *>(s0 + (p.W + 1) * P);
@@ -195,7 +195,9 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
 #pragma unroll
         for (int k = 0; k < U; ++k) {
           // (32-bit row arithmetic: launch_conv bounds n_dup * M * cout_p by 2^31; a 64-bit division costs ~100 instructions)
-          const unsigned r0 = (unsigned)mc[k] / (unsigned)p.m_per_tb, r1 = (unsigned)(p.dup_rows + mc[k]) / (unsigned)p.m_per_tb;
+          // (rows below dup_skip have no second pass: their b1 / o1 are formed from a valid row and never stored or pooled)
+          const unsigned r0 = (unsigned)mc[k] / (unsigned)p.m_per_tb;
+          const unsigned r1 = (unsigned)(p.dup_rows + (mc[k] >= p.dup_skip ? mc[k] - p.dup_skip : mc[k])) / (unsigned)p.m_per_tb;
           b0[k] = *reinterpret_cast<const f32x4 *>(p.tbc + (size_t)r0 * p.tb_stride + cls[k] * p.cout_p + nn);
           b1[k] = *reinterpret_cast<const f32x4 *>(p.tbc + (size_t)r1 * p.tb_stride + cls[k] * p.cout_p + nn);
         }
@@ -209,22 +211,25 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
           o0 += rs[k]; o1 += rs[k];
           if (ok[k] && !p.skip_out) {
             *reinterpret_cast<f32x4 *>(p.out + (size_t)mrow[k] * p.cout_p + n) = o0;
-            *reinterpret_cast<f32x4 *>(p.out + ((size_t)p.dup_rows + mrow[k]) * p.cout_p + n) = o1;
+            if (mrow[k] >= p.dup_skip) *reinterpret_cast<f32x4 *>(p.out + ((size_t)p.dup_rows + mrow[k] - p.dup_skip) * p.cout_p + n) = o1;
           }
           *reinterpret_cast<f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4) = o0;
           *reinterpret_cast<f32x4 *>(stage2 + (row0 + k * (256 / C4)) * P + c4 * 4) = o1;
         }
-        pool_pass(mi, p.pool_out, stage, 2, WK * COPY, (size_t)(p.dup_rows >> 2) * p.cout_p);
+        pool_pass(mi, p.pool_out, stage, 2, WK * COPY, (size_t)((p.dup_rows - p.dup_skip) >> 2) * p.cout_p);
         continue;
       }
       for (int pass = 0; pass < p.n_dup; ++pass) {
+        // dup_skip is a multiple of 256 rows and m0 of the tile height (64 / 128 / 256): a workgroup's rows all lie on one side
+        if (pass && m0 < p.dup_skip) break;                              // (block-uniform) single-pass images: no second pass
         f32x4 o[U];
+        const int shift = pass ? pass * p.dup_rows - p.dup_skip : 0;     // (dup_skip > 0 only with n_dup == 2)
 #pragma unroll
         for (int k = 0; k < U; ++k) {
           o[k] = f32x4{0.f, 0.f, 0.f, 0.f};
           if (ok[k]) {
-            const size_t mg = (size_t)pass * p.dup_rows + mrow[k];
-            const unsigned tr = (unsigned)(pass * p.dup_rows + mrow[k]) / (unsigned)p.m_per_tb;
+            const size_t mg = (size_t)shift + mrow[k];
+            const unsigned tr = (unsigned)(shift + mrow[k]) / (unsigned)p.m_per_tb;
             const f32x4 b = *reinterpret_cast<const f32x4 *>(p.tbc + (size_t)tr * p.tb_stride + cls[k] * p.cout_p + n);
             o[k] = (v[k] + b) * sc + sh;
             if (p.relu) {
@@ -239,7 +244,7 @@ __device__ inline void conv_epilogue(const ConvParams &p, f32x16 (&acc)[MI][NI],
           if (pass) __syncthreads();                   // the previous pass's windows are read
 #pragma unroll
           for (int k = 0; k < U; ++k) *reinterpret_cast<f32x4 *>(stage + (row0 + k * (256 / C4)) * P + c4 * 4) = o[k];
-          pool_pass(mi, p.pool_out + (size_t)pass * (p.dup_rows >> 2) * p.cout_p, stage, 1, 0, 0);
+          pool_pass(mi, p.pool_out + (size_t)(shift >> 2) * p.cout_p, stage, 1, 0, 0);
         }
       }
       continue;

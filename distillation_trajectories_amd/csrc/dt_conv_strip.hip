@@ -132,9 +132,12 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int n_main = CC / p.splits / KC;                           // steps-worth of KC channel chunks in this z slice
+  // steps-worth of KC channel chunks in this z slice; the walk may run past the layer's CC chunks (odd chunk counts): the
+  // weight pack holds zero chunks there (p.ccw per tap, checked by the launcher) and the activation loads are skipped
+  const int n_main = (CC + p.splits * KC - 1) / (p.splits * KC);
   const int cc0 = blockIdx.z * n_main * KC;
-  const int n_chunks = n_main + (p.in2 ? (p.cin2_p >> 4) / KC : 0);
+  const int CC2 = p.cin2_p >> 4;
+  const int n_chunks = n_main + (p.in2 ? (CC2 + KC - 1) / KC : 0);
 
   f32x4 sa0[KC][AP], sa1[KC][AP];
   u32x4 rb[NB];
@@ -145,13 +148,13 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
     for (int i = 0; i < AP; ++i) {
       sa0[kk][i] = f32x4{0.f, 0.f, 0.f, 0.f}; sa1[kk][i] = sa0[kk][i];
       if (ch < n_main) {
-        if (s_ok[i]) {
-          const int cc = cc0 + ch * KC + kk;
+        const int cc = cc0 + ch * KC + kk;
+        if (s_ok[i] && cc < CC) {
           const float *src = (p.in_b && cc >= p.cc_a) ? p.in_b + s_offb[i] + (cc - p.cc_a) * 16 : p.in + s_off[i] + cc * 16;
           sa0[kk][i] = *reinterpret_cast<const f32x4 *>(src);
           sa1[kk][i] = *reinterpret_cast<const f32x4 *>(src + 4);
         }
-      } else if (s_core[i]) {
+      } else if (s_core[i] && (ch - n_main) * KC + kk < CC2) {
         const int c2 = (ch - n_main) * KC + kk;
         const float *src = (p.in2_b && c2 >= p.cc_a) ? p.in2_b + s_offb[i] + (c2 - p.cc_a) * 16 : p.in2 + s_off2[i] + c2 * 16;
         sa0[kk][i] = *reinterpret_cast<const f32x4 *>(src);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   };
   // The weight tiles are visited in a fixed order, so a running pointer replaces per-step index arithmetic:
   // next tap of the chunk group (+tap_stride), first tap of the next group, the skip weights, next skip group.
-  const size_t tap_stride = (size_t)CC * 3 * w_plane, group_stride = (size_t)KC * 3 * w_plane;
+  const size_t tap_stride = (size_t)p.ccw * 3 * w_plane, group_stride = (size_t)KC * 3 * w_plane;
   const __bf16 *wrun = wbase + (size_t)cc0 * 3 * w_plane;
   enum { ADV_NONE = 0, ADV_TAP, ADV_GROUP, ADV_SKIP0, ADV_SKIP };
   auto load_b = [&](int adv) __attribute__((always_inline)) {
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
   // tile keeps its double buffer and a step has one barrier.
   constexpr bool DIRECT = MI * KW <= 2 && KC >= 2 && ABL == 0;   // (K = 16 steps: 3 waves per SIMD leave no registers for the two sets)
   f32x4 ga0[KW][MI][2], ga1[KW][MI][2];
-  const int n_skip = p.in2 ? (p.cin2_p >> 4) / KC : 0;
+  const int n_skip = p.in2 ? (CC2 + KC - 1) / KC : 0;
   auto load_a = [&](f32x4 (&g)[KW][MI][2], int s2) __attribute__((always_inline)) {
 #pragma unroll
     for (int kw = 0; kw < KW; ++kw)
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void conv_strip_bf16x6_kernel
         const int c2 = s2 * KC + wk * KW + kw;
         const int m = m0 + wm * (MI * 32) + mi * 32 + l31;
         g[kw][mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; g[kw][mi][1] = g[kw][mi][0];
-        if (m < p.M) {
+        if (m < p.M && c2 < CC2) {
           const float *src = (p.in2_b && c2 >= p.cc_a) ? p.in2_b + (size_t)m * p.b_stride + (c2 - p.cc_a) * 16 + half * 8
                                                        : p.in2 + (size_t)m * p.cin2_p + c2 * 16 + half * 8;
           g[kw][mi][0] = *reinterpret_cast<const f32x4 *>(src);
@@ -530,7 +533,7 @@ int launch_conv_strip(const ConvParams &p_in, int bm, int bn, int prec, hipStrea
   if (p.ksize != 3 || p.tap_lo != 0 || p.tap_hi != 9 || p.splits < 1 || prec < 3 || prec > 5) return DT_E_ARG;
   if (prec == 5 && (bm > 128 || (bm == 128 && bn == 128))) return DT_E_ARG;
   if (kc == 4 && p.W + 1 > 32) return DT_E_SHAPE;
-  if ((p.cin_p >> 4) % (p.splits * kc) || (p.in2 && (p.cin2_p >> 4) % kc)) return DT_E_ARG;
+  if (!chunks_fit(p.cin_p >> 4, p.ccw, p.splits * kc) || (p.in2 && !chunks_fit(p.cin2_p >> 4, p.ccw2, kc))) return DT_E_ARG;
   if (p.W + 1 > 64) return DT_E_SHAPE;                             // 2 (3) strip items per thread cover BM + 2(W+1) <= 256 (384) rows
   if (bm == 256 && bn != 64) return DT_E_ARG;
   dim3 grid((p.M + bm - 1) / bm, p.n_p / bn, p.splits);

@@ -56,8 +56,11 @@ __device__ inline float bilinear_blend(float v00, float v01, float v10, float v1
 constexpr int kChanPad = 16;   // activation channel granularity (= BK of the conv GEMM)
 constexpr int kNPad = 64;      // packed-weight N granularity (smallest BN tile)
 constexpr int kBlocks = 8;
+constexpr int kChunkPad = 4;   // chunk granularity of the split-bf16 weight packs (see ConvParams::ccw)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// whether a walk of `cc` chunks in groups of `div` (K chunks per step x split-K slices) stays inside a pack of `ccw` chunks
+inline bool chunks_fit(int cc, int ccw, int div) { return div >= 1 && round_up(cc, div) <= ccw; }
 
 // One convolution expressed as an implicit GEMM over NHWC activations:
 //   out[m][n] = epilogue( sum_{tap,c} in[pixel(m)+tap][c] * w[tap][c][n] )
@@ -119,8 +122,16 @@ struct ConvParams {
   // at row offset pass * dup_rows (pass * dup_rows / 4 for the pooled tensor)
   const float *tbc;
   int n_dup, dup_rows;
+  // mixed batches (dt_sample_trajectory_mixed): the first dup_skip rows of the launch (images that take ONE pass) have no second
+  // pass; pass 1 of row m >= dup_skip goes to row dup_rows + m - dup_skip.  A multiple of H * W (whole images).
+  int dup_skip;
   int skip_out;        // n_dup mode: do not store `out` (enc1's full-resolution output has no reader but the pool)
   int dup_stage2;      // n_dup == 2: the launch's LDS holds a second epilogue stage (set by the strip launcher)
+  // 16-channel weight chunks per tap in the packs behind `w` / `w2`.  The split-bf16 packs are zero-padded to a multiple
+  // of kChunkPad chunks so that the kernels that multiply 2 or 4 chunks per step (and split them across waves) also run
+  // layers with an odd chunk count (cin_p = 48, 80, 112, 208, 240: size factors 0.3, 0.4, 0.6, 0.8, 0.9): the walk is
+  // ceil(chunks / step) steps, the activation loads of a chunk >= cin_p / 16 are replaced by zeros
+  int ccw, ccw2;
   int ablate;          // timing experiments only (wrong results): 1 no barrier, 2 no LDS reads, 3 no MFMA, 4 no staging
 };
 
@@ -130,7 +141,8 @@ int launch_conv_strip(const ConvParams &p, int bm, int bn, int prec, hipStream_t
 int strip_kc(int prec, int bm, int bn);                         // 16-channel chunks per step of a strip arithmetic code
 // whether the strip kernel can run a bm x bn tile with kc chunks per step on rows of W pixels (staging reach, LDS)
 bool strip_admissible(int W, int bm, int bn, int prec);
-int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int n_p,
+// cin_w: padded input channels per tap of the pack (>= cin_p, multiple of 16 * kChunkPad; zeros beyond cin_p)
+int launch_pack_conv_bf16x3(const float *w_oihw, void *wp, int cout, int cin, int ksize, int cin_p, int cin_w, int n_p,
                             int split_c, int split_cp, hipStream_t s);
 struct ConvChoice { int bm, bn, splits, prec, fuse; };
 ConvChoice heuristic_choice(int M, int n_p, int taps);

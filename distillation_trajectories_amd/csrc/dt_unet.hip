@@ -23,7 +23,7 @@ int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec
                       float w_scalar, float *out, int B, int E, hipStream_t s);
 int launch_cfg_update_lowres(int rule, const float *x, const float *lowres_u, const float *lowres_c, const float *z,
                              const int32_t *z_row, long long z_shift, const float coef[4], int has_noise, const float *w,
-                             float w_scalar, float *out, int B, int C, int H, int W, hipStream_t s);
+                             float w_scalar, float *out, int B, int C, int H, int W, int b_single, hipStream_t s);
 int launch_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, int E, double *out, hipStream_t s);
 int launch_wasserstein(const float *X, const float *Y, int n, int B, int E, const int32_t *index,
                        const int32_t *index_row, int n_idx, double *out, hipStream_t s);
@@ -89,6 +89,7 @@ struct BlockW {
   int cin, cout;          // real channels
   int cin_p, cout_p, n_p; // padded
   int split_c, split_cp;  // concat split of the input channels (== cin, cin_p when no concat)
+  int cin_w, cout_w;      // input channels per tap of the split-bf16 packs of conv1 (and the skip) / conv2: cin_p / cout_p padded to kChunkPad chunks
   bool has_res;
   float *w1, *w2, *wr;    // packed conv weights (fp32 tiles)
   float *w1b, *w2b, *wrb; // the same weights split into three bf16 planes (dt_conv_bf16.hip)
@@ -111,8 +112,14 @@ struct LoopGraph {
   hipGraph_t graph;
 };
 
+// how a forward shape (Bt rows) splits into images: recorded by every forward so that the tuning / reporting hooks, which are
+// keyed by the row count alone, describe the launches the forward really issues (enc1 runs over the images, not the rows)
+struct ShapeInfo { int Bt, H, W, imgs, single; };
+
 struct dt_unet {
   std::vector<TunedShape> tuned;
+  mutable std::vector<ShapeInfo> shapes;
+  mutable std::mutex shape_mu;
   // replay cache of the sampler loop (not part of the handle's logical state, hence mutable + its own lock: the
   // sampler may be entered from several host threads); dropped whenever the launch plan changes
   mutable std::vector<LoopGraph> graphs;
@@ -191,9 +198,28 @@ const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W) {
 
 // Parameters of conv slot `slot` (0 = 1x1 skip, 1 = conv1, 2 = conv2) of block j; returns false when the
 // block has no such launch (identity skips, and enc1 whose skip is recomputed in conv2's epilogue).
+void shape_images(const dt_unet *u, int Bt, int H, int W, int &imgs, int &single) {
+  {
+    std::lock_guard<std::mutex> lock(u->shape_mu);
+    for (const ShapeInfo &si : u->shapes)
+      if (si.Bt == Bt && si.H == H && si.W == W) { imgs = si.imgs; single = si.single; return; }
+  }
+  imgs = Bt % 2 == 0 ? Bt / 2 : Bt;   // never run yet: the sampler's two-pass CFG shape
+  single = 0;
+}
+
+void note_shape(const dt_unet *u, int Bt, int H, int W, int imgs, int single) {
+  std::lock_guard<std::mutex> lock(u->shape_mu);
+  for (ShapeInfo &si : u->shapes)
+    if (si.Bt == Bt && si.H == H && si.W == W) { si.imgs = imgs; si.single = single; return; }
+  u->shapes.push_back(ShapeInfo{Bt, H, W, imgs, single});
+}
+
+// x_imgs images make up the Bt rows: every image once (pass 0), then the images from x_single on a second time (pass 1) when
+// Bt > x_imgs.  x_imgs <= 0 (tuning / reporting contexts): what the last forward of this row count used.
 bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, const Plan &pl, int Bt, const float *tb,
-               int tb_div, const ConvChoice *choice, ConvParams &p, int x_imgs = 0) {
-  if (x_imgs <= 0) x_imgs = Bt % 2 == 0 ? Bt / 2 : Bt;   // tuning / reporting contexts: the sampler's two-pass CFG shape
+               int tb_div, const ConvChoice *choice, ConvParams &p, int x_imgs = 0, int x_single = 0) {
+  if (x_imgs <= 0) shape_images(u, Bt, pl.H[0], pl.W[0], x_imgs, x_single);
   const BlockW &k = u->blk[j];
   const int h = pl.H[j], w = pl.W[j];
   const bool dot = h == 1 && w == 1;   // a 1x1 image only ever sees the centre tap of a padded 3x3 kernel
@@ -226,9 +252,9 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
       // the C-channel skip of enc1 is recomputed in the epilogue from the patches' centre taps (k = 9c+4)
       p.x3 = in; p.w3 = k.w3; p.x3_hw = h * w; p.x3_imgs = x_imgs; p.x3_c = u->desc.channels;   // `in` is the NCHW image
       taps = 1;   // keeps the fused (non-split) epilogue
-      if (u->share_enc1 && Bt % x_imgs == 0) {   // one launch over the x_imgs images for all Bt / x_imgs passes
+      if (u->share_enc1 && (Bt + x_single) % x_imgs == 0) {   // one launch over the x_imgs images for all their passes
         p.M = x_imgs * h * w;
-        p.n_dup = Bt / x_imgs; p.dup_rows = p.M; p.tbc = tb + u->tb_cols;
+        p.n_dup = (Bt + x_single) / x_imgs; p.dup_rows = p.M; p.dup_skip = x_single * h * w; p.tbc = tb + u->tb_cols;
         p.skip_out = u->head_fusion ? 1 : 0;   // decided below once pool_out is known: only the pool reads enc1's output
       }
     } else {
@@ -247,13 +273,15 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
   if (c.prec == 2) c.prec = 1;
   if (c.prec >= 3 && (p.tap_hi - p.tap_lo != 9 || !strip_admissible(p.W, 64, 64, 3))) c.prec = 1;   // full 3x3 walks of rows <= 63 px only
   if (c.prec == 5 && (c.bm > 128 || (c.bm == 128 && c.bn == 128))) c.prec = 4;   // K split across waves: tiles below 128 x 128
-  if (c.prec == 5 && (p.cin_p >> 4) % strip_kc(5, c.bm, c.bn)) c.prec = 4;
-  if (c.prec == 4 && (p.cin_p >> 4) % 2) c.prec = 3;                // two chunks per step need an even chunk count
+  // weight chunks per tap of the packs: the split-bf16 packs carry zero chunks up to a multiple of kChunkPad, so layers with an
+  // odd chunk count also run the kernels that multiply 2 / 4 chunks per step
+  const int cw_main = round_up(p.cin_p, 16 * kChunkPad) >> 4;
   if (c.bm == 256 && c.prec < 3) c.bm = 128;                        // the 256-row tile exists in the strip kernels only
   if (p.x3 || j == 0 || p.M > kSplitMaxRows) c.splits = 1;          // (enc1: no slab; its conv2 keeps the fused x3 epilogue)
-  if (c.prec >= 3 ? ((p.cin_p >> 4) % (c.splits * strip_kc(c.prec, c.bm, c.bn)) != 0)
+  if (c.prec >= 3 ? !chunks_fit(p.cin_p >> 4, cw_main, c.splits * strip_kc(c.prec, c.bm, c.bn))
                   : (((p.tap_hi - p.tap_lo) * (p.cin_p >> 4)) % c.splits != 0)) c.splits = 1;
   p.bm = c.bm; p.bn = c.bn; p.splits = c.splits; p.prec = c.prec;
+  p.ccw = c.prec >= 1 ? cw_main : p.cin_p >> 4;
   // encoder blocks enc1..enc4 feed a 2x2 max pool: folded into this launch's staged epilogue where a 32-row tile holds
   // whole row pairs (W a power of two <= 16); split launches pool in their slab-summing epilogue kernel instead
   if (slot == 2 && j <= 3 && h % 2 == 0 && w % 2 == 0 && (c.splits > 1 || (w <= 16 && (w & (w - 1)) == 0))) p.pool_out = ws + pl.pool[j];
@@ -265,10 +293,11 @@ bool conv_slot(const dt_unet *u, int j, int slot, const float *in, float *ws, co
     p.head_w = u->final_w; p.head_b = u->final_b; p.head_out = ws + pl.lowres;
     p.head_c = u->desc.channels; p.head_cin = u->desc.dims[0];
   }
-  if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0 && !(c.prec >= 4 && (k.cin_p >> 4) % strip_kc(c.prec, c.bm, c.bn))) {
+  if (slot == 2 && c.fuse && c.splits == 1 && k.has_res && j > 0) {
     // conv2 with the block's 1x1 skip folded into its K walk (the slot-0 launch is then skipped)
     p.add = nullptr;
     p.in2 = in; p.w2 = c.prec >= 1 ? k.wrb : k.wr; p.bias2 = k.hr; p.cin2_p = k.cin_p; p.cin2_real = k.cin;
+    p.ccw2 = c.prec >= 1 ? k.cin_w >> 4 : k.cin_p >> 4;
   }
   return true;
 }
@@ -286,7 +315,7 @@ bool concat_in_place(const dt_unet *u, int j, float *ws, const Plan &pl, int Bt,
 }
 
 int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &pl, int Bt, const float *tb, int tb_div,
-              const TunedShape *tuned, hipStream_t s, int x_imgs) {
+              const TunedShape *tuned, hipStream_t s, int x_imgs, int x_single) {
   ConvParams p;
   bool fused_skip = false;
   if (u->blk[j].has_res && j > 0) {   // is conv2 going to fold the skip in?
@@ -297,14 +326,15 @@ int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &p
   const bool in_place = concat_in_place(u, j, ws, pl, Bt, tb, tb_div, tuned);
   if (j == 0) {
     const BlockW &k = u->blk[0];
-    const bool shared = u->share_enc1 && Bt % x_imgs == 0;   // then the passes' time biases enter in conv2's epilogue
+    const bool shared = u->share_enc1 && (Bt + x_single) % x_imgs == 0;   // then the passes' time biases enter in conv2's epilogue
+    if (!shared && x_single) return DT_E_ARG;                // mixed batches exist in the shared-enc1 formulation only
     const int st = launch_first_conv(in, k.w1, k.s1, k.h1, shared ? nullptr : tb + k.tb_off, u->tb_stride, tb_div, ws + pl.h[0], x_imgs,
                                      shared ? 1 : Bt / x_imgs, u->desc.channels, pl.H[0], pl.W[0], k.cout, k.cout_p, s);
     if (st) return st;
   }
   for (int slot = 0; slot < 3; ++slot) {
     if (slot == 0 && fused_skip) continue;
-    if (!conv_slot(u, j, slot, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][slot] : nullptr, p, x_imgs)) continue;
+    if (!conv_slot(u, j, slot, in, ws, pl, Bt, tb, tb_div, tuned ? &tuned->c[j][slot] : nullptr, p, x_imgs, x_single)) continue;
     if (in_place) {
       const int skip = 8 - j;            // dec3<-enc4(3), dec2<-enc3(2), dec1<-enc2(1)
       p.cc_a = u->blk[j].split_cp >> 4;
@@ -318,11 +348,15 @@ int run_block(const dt_unet *u, int j, const float *in, float *ws, const Plan &p
   return DT_OK;
 }
 
+// B images; the first B_single of them take one pass, the others n_pass (B_single > 0 needs n_pass == 2): rows
+// [pass 0 of all B images | pass 1 of images B_single .. B-1]
 int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int W, const float *tb, int tb_div,
-                 float *eps, float *ws, size_t ws_bytes, hipStream_t s) {
+                 float *eps, float *ws, size_t ws_bytes, hipStream_t s, int B_single = 0) {
   if (!u || !x || !tb || !ws) return DT_E_NULL;
   if (B < 1 || n_pass < 1 || tb_div < 1 || H < 16 || W < 16 || H % 16 || W % 16) return DT_E_SHAPE;
-  const int Bt = B * n_pass;
+  if (B_single < 0 || B_single >= B || (B_single && n_pass != 2)) return DT_E_ARG;
+  const int Bt = B * n_pass - B_single * (n_pass - 1);
+  note_shape(u, Bt, H, W, B, B_single);
   const Plan pl = make_plan(u, Bt, H, W);
   if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
   const TunedShape *tuned = find_tuned(u, Bt, H, W);
@@ -345,7 +379,7 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
       if (st) return st;
       cur = ws + pl.cat[j - 5];
     }
-    st = run_block(u, j, cur, ws, pl, Bt, tb, tb_div, tuned, s, B);
+    st = run_block(u, j, cur, ws, pl, Bt, tb, tb_div, tuned, s, B, B_single);
     if (st) return st;
   }
   {   // head at the low resolution (unless dec1.conv2's epilogue already produced it), then the 3-channel upsample
@@ -417,6 +451,7 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
       k.split_c = cin[j]; k.split_cp = k.cin_p;
     }
     k.has_res = cin[j] != cout[j];
+    k.cin_w = round_up(k.cin_p, 16 * kChunkPad); k.cout_w = round_up(k.cout_p, 16 * kChunkPad);
     for (int t = 0; t < DT_BT_COUNT; ++t) {
       const bool optional = t == DT_BT_RES_W || t == DT_BT_RES_B;
       if (!bt[j * DT_BT_COUNT + t] && (!optional || k.has_res)) { delete u; return DT_E_NULL; }
@@ -425,9 +460,9 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
     o_w2[j] = bump.take((size_t)9 * k.cout_p * k.n_p);
     o_wr[j] = k.has_res ? bump.take(j == 0 ? (size_t)4 * k.n_p : (size_t)k.cin_p * k.n_p) : 0;
     o_ss[j] = bump.take((size_t)6 * k.n_p);
-    o_w1b[j] = j == 0 ? 0 : bump.take((size_t)9 * k.cin_p * k.n_p * 3 / 2);
-    o_w2b[j] = bump.take((size_t)9 * k.cout_p * k.n_p * 3 / 2);
-    o_wrb[j] = (k.has_res && j > 0) ? bump.take((size_t)k.cin_p * k.n_p * 3 / 2) : 0;
+    o_w1b[j] = j == 0 ? 0 : bump.take((size_t)9 * k.cin_w * k.n_p * 3 / 2);
+    o_w2b[j] = bump.take((size_t)9 * k.cout_w * k.n_p * 3 / 2);
+    o_wrb[j] = (k.has_res && j > 0) ? bump.take((size_t)k.cin_w * k.n_p * 3 / 2) : 0;
     k.tb_off = tb;
     tb += k.cout_p;
   }
@@ -468,10 +503,10 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
     if (!st) st = launch_pack_conv(t[DT_BT_CONV2_W], k.w2, k.cout, k.cout, 3, k.cout_p, k.n_p, k.cout, k.cout_p, s);
     if (!st && k.has_res && j > 0)
       st = launch_pack_conv(t[DT_BT_RES_W], k.wr, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
-    if (!st && j > 0) st = launch_pack_conv_bf16x3(t[DT_BT_CONV1_W], k.w1b, k.cout, k.cin, 3, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
-    if (!st) st = launch_pack_conv_bf16x3(t[DT_BT_CONV2_W], k.w2b, k.cout, k.cout, 3, k.cout_p, k.n_p, k.cout, k.cout_p, s);
+    if (!st && j > 0) st = launch_pack_conv_bf16x3(t[DT_BT_CONV1_W], k.w1b, k.cout, k.cin, 3, k.cin_p, k.cin_w, k.n_p, k.split_c, k.split_cp, s);
+    if (!st) st = launch_pack_conv_bf16x3(t[DT_BT_CONV2_W], k.w2b, k.cout, k.cout, 3, k.cout_p, k.cout_w, k.n_p, k.cout, k.cout_p, s);
     if (!st && k.has_res && j > 0)
-      st = launch_pack_conv_bf16x3(t[DT_BT_RES_W], k.wrb, k.cout, k.cin, 1, k.cin_p, k.n_p, k.split_c, k.split_cp, s);
+      st = launch_pack_conv_bf16x3(t[DT_BT_RES_W], k.wrb, k.cout, k.cin, 1, k.cin_p, k.cin_w, k.n_p, k.split_c, k.split_cp, s);
     if (!st && j == 0) st = launch_pack_res3(t[DT_BT_RES_W], t[DT_BT_RES_B], k.w3, k.cout, C, k.n_p, s);
     if (!st && j == 0 && u->share_enc1) st = launch_pack_tap_major(t[DT_BT_CONV2_W], S + o_w2t, k.cout, k.cout, k.cout_p, s);
     if (!st) st = launch_fold_bn(t[DT_BT_CONV1_B], t[DT_BT_BN1_G], t[DT_BT_BN1_B], t[DT_BT_BN1_MEAN], t[DT_BT_BN1_VAR],
@@ -600,7 +635,6 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
         if (skip_mask & (1 << prec)) continue;
         const bool strip_ok = full3x3 && strip_admissible(p.W, 64, 64, 3);   // some strip tile fits this row width
         if (prec >= 3 && !strip_ok) continue;
-        if (prec >= 4 && (p.cin_p >> 4) % 2) continue;
         if (prec == 1 && strip_ok) continue;                                  // the plain kernel competes where the strip one cannot run
       for (int bm = 64; bm <= 256; bm *= 2)
         for (int bn = 64; bn <= 128; bn += 64) {
@@ -613,16 +647,17 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
           const long long tiles = (long long)((p.M + bm - 1) / bm) * (p.n_p / bn);
           for (int sp = 1; sp <= (can_split ? 9 : 1); sp *= ((prec >= 3 || !walk9) ? 2 : 3))
           for (int fuse = 0; fuse <= ((can_fuse && sp == 1) ? 1 : 0); ++fuse) {
-            if ((prec >= 3 || !walk9) && (p.cin_p >> 4) % (sp * (prec >= 3 ? strip_kc(prec, bm, bn) : 1))) continue;
-            if (prec >= 4 && fuse && (kw.cin_p >> 4) % strip_kc(prec, bm, bn)) continue;
+            if (prec >= 3 ? !chunks_fit(p.cin_p >> 4, round_up(p.cin_p, 16 * kChunkPad) >> 4, sp * strip_kc(prec, bm, bn))
+                          : (!walk9 && (p.cin_p >> 4) % sp)) continue;
             if (prec >= 3 && !strip_admissible(p.W, bm, bn, prec)) continue;   // LDS footprint of this tile
             if (sp > 1 && tiles * (sp / 2) >= 1024) continue;          // already >= 4 workgroups per CU without this split
             ConvParams q = p;
             q.bm = bm; q.bn = bn; q.splits = sp; q.prec = prec;
             q.w = prec ? (slot == 0 ? kw.wrb : (slot == 1 ? kw.w1b : kw.w2b)) : (slot == 0 ? kw.wr : (slot == 1 ? kw.w1 : kw.w2));
+            q.ccw = prec ? round_up(p.cin_p, 16 * kChunkPad) >> 4 : p.cin_p >> 4;
             if (fuse) {
               q.add = nullptr; q.in2 = in; q.w2 = prec ? kw.wrb : kw.wr; q.bias2 = kw.hr; q.cin2_p = kw.cin_p;
-              q.cin2_real = kw.cin;
+              q.cin2_real = kw.cin; q.ccw2 = prec ? kw.cin_w >> 4 : kw.cin_p >> 4;
             }
             const float ms = measure(q, 3);
             if (ms < 0.f) continue;
@@ -788,26 +823,32 @@ int dt_cfg_update(int rule, const float *x, const float *eu, const float *ec, co
   return launch_cfg_update(rule, x, eu, ec, z, z_row, 0, coef, has_noise, w, w_scalar, out, B, E, (hipStream_t)stream);
 }
 
+// tb_div rows of a step's forward share one time-bias row (0: one row per pass, i.e. tb_div = B); B_single: see forward_impl
 static int sample_loop(const dt_unet *h, int rule, int B, int n_pass, int H, int W, int n_steps, const float *tb,
                        const float *coef, const int32_t *has_noise, const float *z, const int32_t *z_row,
                        const int64_t *z_shift, const float *w, float w_scalar, float *traj, float *eps_scratch,
-                       void *ws, size_t ws_bytes, hipStream_t s) {
+                       void *ws, size_t ws_bytes, hipStream_t s, int B_single = 0, int tb_div = 0) {
   const int E = h->desc.channels * H * W;
   const size_t slot = (size_t)B * E;
-  if (make_plan(h, B * n_pass, H, W).total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
-  const float *lowres = (const float *)ws + lowres_offset(h, B * n_pass, H, W);
+  const int Bt = B * n_pass - B_single * (n_pass - 1);
+  if (!tb_div) tb_div = B;
+  if (Bt % tb_div) return DT_E_ARG;
+  const int tb_rows = Bt / tb_div;         // time-bias rows per step
+  if (make_plan(h, Bt, H, W).total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
+  const float *lowres = (const float *)ws + lowres_offset(h, Bt, H, W);
   (void)eps_scratch;                       // kept in the ABI: callers still hand in the scratch the unfused path used
   for (int i = 0; i < n_steps; ++i) {
     const float *x = traj + (size_t)i * slot;
     float *xn = traj + (size_t)(i + 1) * slot;
     const bool dead = rule == DT_RULE_ENGINE && !has_noise[i];   // t == 0: the prediction is never used
     if (!dead) {      // the forward stops at the low-resolution head output; the update interpolates it (no eps tensor)
-      int st = forward_impl(h, x, B, n_pass, H, W, tb + (size_t)i * n_pass * h->tb_stride, B, nullptr, (float *)ws, ws_bytes, s);
+      int st = forward_impl(h, x, B, n_pass, H, W, tb + (size_t)i * tb_rows * h->tb_stride, tb_div, nullptr, (float *)ws, ws_bytes, s, B_single);
       if (st) return st;
     }
-    int st = launch_cfg_update_lowres(rule, x, lowres, n_pass == 2 ? lowres + (size_t)B * (H / 2) * (W / 2) * 4 : nullptr, z, z_row,
+    // second-pass rows start at row B and belong to images B_single .. B-1: indexed by image through a pointer shifted back
+    int st = launch_cfg_update_lowres(rule, x, lowres, n_pass == 2 ? lowres + (size_t)(B - B_single) * (H / 2) * (W / 2) * 4 : nullptr, z, z_row,
                                       z_shift ? (long long)z_shift[i] : 0, coef + 4 * i, has_noise[i], w, w_scalar, xn, B,
-                                      h->desc.channels, H, W, s);
+                                      h->desc.channels, H, W, B_single, s);
     if (st) return st;
   }
   return DT_OK;
@@ -862,6 +903,23 @@ int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, i
   hm->graphs.push_back(std::move(g));
   if (getenv("DT_GRAPH_DEBUG")) fprintf(stderr, "[dt_hip] captured sampler loop: %d steps, batch %d -> graph #%zu\n", n_steps, B, hm->graphs.size());
   return (int)hipGraphLaunch(hm->graphs.back().exec, s);
+}
+
+int dt_sample_trajectory_mixed(const dt_unet *h, int rule, int B, int B_single, int H, int W, int n_steps, const float *tb,
+                               int tb_div, const float *coef, const int32_t *has_noise, const float *z, const int32_t *z_row,
+                               const int64_t *z_shift, const float *w, float *traj, void *ws, size_t ws_bytes, void *stream) {
+  if (!h || !tb || !coef || !has_noise || !traj || !ws || !w) return DT_E_NULL;
+  if (n_steps < 0 || rule < 0 || rule > DT_RULE_MANAGER || B < 2 || B_single < 1 || B_single >= B || tb_div < 1) return DT_E_ARG;
+  if ((2 * B - B_single) % tb_div || B_single % tb_div || !h->share_enc1) return DT_E_ARG;   // a time-bias row never straddles the single / CFG boundary
+  return sample_loop(h, rule, B, 2, H, W, n_steps, tb, coef, has_noise, z, z_row, z_shift, w, 1.f, traj, nullptr, ws, ws_bytes,
+                     (hipStream_t)stream, B_single, tb_div);
+}
+
+int dt_unet_forward_mixed(const dt_unet *h, const float *x, int B, int B_single, int H, int W, const float *tb, int tb_div,
+                          float *eps, void *ws, size_t ws_bytes, void *stream) {
+  if (!eps || !h) return DT_E_NULL;
+  if (B_single < 1 || B_single >= B || tb_div < 1 || (2 * B - B_single) % tb_div || B_single % tb_div || !h->share_enc1) return DT_E_ARG;
+  return forward_impl(h, x, B, 2, H, W, tb, tb_div, eps, (float *)ws, ws_bytes, (hipStream_t)stream, B_single);
 }
 
 // an empty kernel with a recognisable name: lets an external profiler (rocprofv3 traces) bracket a region of the stream

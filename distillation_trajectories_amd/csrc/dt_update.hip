@@ -28,6 +28,7 @@ struct UpdateArgs {
   long long z_shift;   // added to the z row index (rows of E floats)
   int has_noise, B, E4;
   int lh, lw, hw;
+  int b_single;        // rows [0, b_single) take the first prediction as it is (single-pass images of a mixed batch)
 };
 
 template <int RULE>
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void cfg_update_kernel(const UpdateArgs a) {
     const float4 xv = x4[i];
     if (RULE == DT_RULE_ENGINE && !a.has_noise) { o4[i] = xv; continue; }   // t == 0: x is recorded unchanged
     float4 ev = LOWRES ? eps_from_lowres(a.eu, b, e, a) : eu4[i];
-    if (a.ec) {
+    if (a.ec && b >= a.b_single) {
       const float4 cv = LOWRES ? eps_from_lowres(a.ec, b, e, a) : ec4[i];
       const float w = a.w ? a.w[b] : a.w_scalar;
       ev.x = ev.x + w * (cv.x - ev.x);
@@ -112,7 +113,7 @@ int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec
   if (!x || !eu || !out || !coef) return DT_E_NULL;
   if (has_noise && !z) return DT_E_NULL;
   if (B <= 0 || E <= 0 || E % 4) return DT_E_SHAPE;
-  UpdateArgs a{x, eu, ec, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4, 0, 0, 0};
+  UpdateArgs a{x, eu, ec, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4, 0, 0, 0, 0};
   const size_t total = (size_t)B * (E / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   // algorithmic bytes: read x + read z + write x' = 3*E*4 per sample-step (+ eps reads)
@@ -128,16 +129,18 @@ int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec
 }
 
 // the same step with the prediction taken from the low-resolution head outputs of the two passes (lowres_u, lowres_c:
-// [B][H/2][W/2][4]; lowres_c == nullptr: one pass)
+// [B][H/2][W/2][4]; lowres_c == nullptr: one pass).  b_single > 0 (mixed batch): images [0, b_single) have no second pass
+// and lowres_c is indexed from image b_single on (the caller passes the second pass's first row shifted back by b_single images).
 int launch_cfg_update_lowres(int rule, const float *x, const float *lowres_u, const float *lowres_c, const float *z,
                              const int32_t *z_row, long long z_shift, const float coef[4], int has_noise, const float *w,
-                             float w_scalar, float *out, int B, int C, int H, int W, hipStream_t s) {
+                             float w_scalar, float *out, int B, int C, int H, int W, int b_single, hipStream_t s) {
   if (!x || !lowres_u || !out || !coef) return DT_E_NULL;
   if (has_noise && !z) return DT_E_NULL;
   const int E = C * H * W;
   if (B <= 0 || E <= 0 || W % 4 || H % 2 || W % 2) return DT_E_SHAPE;
+  if (b_single < 0 || b_single > B) return DT_E_ARG;
   UpdateArgs a{x, lowres_u, lowres_c, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4,
-               H / 2, W / 2, H * W};
+               H / 2, W / 2, H * W, b_single};
   const size_t total = (size_t)B * (E / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   ProfileScope prof(KC_UPDATE, 0.0, 4.0 * B * E * (2.0 + (has_noise ? 1.0 : 0.0)) + 4.0 * B * H * W * (lowres_c ? 2.0 : 1.0), s);

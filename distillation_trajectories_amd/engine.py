@@ -257,6 +257,46 @@ class UNetHandle:
         run()
         return eps
 
+    def forward_mixed(self, x, tb, b_single, tb_div, tune=None):
+        """eps[2B - b_single, C, H, W] of a mixed batch (dt_unet_forward_mixed): images [0, b_single) take one pass,
+        the others two; rows [pass 0 of all images | pass 1 of images b_single..]; row r uses tb[r // tb_div]."""
+        _require_cuda(x, "x")
+        x = x.contiguous().float()
+        B, C, H, W = x.shape
+        rows = 2 * B - b_single
+        eps = torch.empty(rows, C, H, W, dtype=torch.float32, device=self.device)
+        ws = self.workspace(rows, H, W)
+
+        def run():
+            with torch.cuda.device(self.device):
+                check(self.lib.dt_unet_forward_mixed(self.h, ptr(x), B, b_single, H, W, ptr(tb), tb_div, ptr(eps), ptr(ws),
+                                                     c_size_t(ws.numel()), stream_ptr()), "dt_unet_forward_mixed")
+        if self._wants_tuning(rows, H, W, tune):
+            run()
+            self.autotune(rows, H, W)
+        run()
+        return eps
+
+    def sample_mixed(self, rule, traj, H, W, tb, tb_div, b_single, coef, has_noise, z, z_row, z_shift, w):
+        """len(coef) reverse steps in place on traj[(n_steps+1), B, E] of a mixed batch (dt_sample_trajectory_mixed)."""
+        _require_cuda(traj, "traj")
+        n_steps = len(coef)
+        B = traj.shape[1]
+        rows = 2 * B - b_single
+        assert traj.shape[0] == n_steps + 1 and traj.is_contiguous() and traj.dtype == torch.float32
+        coef_c = (c_float * (4 * n_steps))(*[float(v) for row in coef for v in (list(row) + [0.0] * 4)[:4]])
+        noise_c = (c_int32 * n_steps)(*[int(bool(v)) for v in has_noise])
+        shift_c = (c_int64 * n_steps)(*[int(v) for v in (z_shift if z_shift is not None else [0] * n_steps)])
+        ws = self.workspace(rows, H, W)
+        if n_steps and self._wants_tuning(rows, H, W, None):
+            per_step = rows // tb_div
+            self.forward_mixed(traj[0].reshape(B, self.channels, H, W), tb[:per_step].contiguous(), b_single, tb_div, tune=True)
+        with torch.cuda.device(self.device):
+            check(self.lib.dt_sample_trajectory_mixed(self.h, rule, B, b_single, H, W, n_steps, ptr(tb), tb_div, coef_c, noise_c,
+                                                      ptr(z), ptr(z_row), shift_c, ptr(w), ptr(traj), ptr(ws),
+                                                      c_size_t(ws.numel()), stream_ptr()), "dt_sample_trajectory_mixed")
+        return traj
+
     def _wants_tuning(self, batch_total, H, W, tune):
         """Autotune big shapes once (>= 16k GEMM rows at full resolution) unless DT_AUTOTUNE=0."""
         if (batch_total, H, W) in self._tuned:

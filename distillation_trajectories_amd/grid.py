@@ -90,19 +90,22 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
             index, index_row = _upload(tables), rows
         handles = [engine.UNetHandle.for_module(m) for m in [teacher] + list(students)]
         # launch-plan autotuning times kernels with events: do it before anything runs concurrently
-        plans = [(1, count)] + ([(2, count * sum(1 for gs in scales if gs is not None and gs > 1.0))] if any(
-            gs is not None and gs > 1.0 for gs in scales) else [])
+        from .analysis.trajectory_engine import _merge_plans, uses_cfg
+        n_cfg = sum(1 for gs in scales if uses_cfg(gs))
+        merged = n_cfg and n_cfg < len(scales) and _merge_plans()
+        plans = [] if merged else [(1, count)] + ([(2, count * n_cfg)] if n_cfg else [])
         for h in handles:
+            if merged and h._wants_tuning((1 + 2 * n_cfg) * count, H, H, None):
+                B = (1 + n_cfg) * count
+                tb = h.time_bias([T - 1] * (1 + 2 * n_cfg), [0] * (1 + 2 * n_cfg))
+                x = table[torch.arange(B, device=device) % table.shape[0]]            # real noise: zeros clock differently
+                h.forward_mixed(x.reshape(B, C, H, H), tb, count, count, tune=True)
             for n_pass, B in plans:
                 if B and h._wants_tuning(n_pass * B, H, H, None):
                     tb = h.time_bias([T - 1] * n_pass, [0] * n_pass)
                     x = table[torch.arange(B, device=device) % table.shape[0]]        # real noise: zeros clock differently
                     h.forward(x.reshape(B, C, H, H), tb, n_pass, B, tune=True)
         main = torch.cuda.current_stream()
-        from .analysis.trajectory_engine import uses_cfg
-        n_guided = sum(1 for gs in scales if uses_cfg(gs))
-        group_sizes = ([1] if n_guided < len(scales) else []) + ([n_guided] if n_guided else [])   # G of the plain / guided plan
-        row_sets = [None if index_row is None else index_row.repeat(G).to(device) for G in group_sizes]
         n_streams = max(1, min(len(students), streams or int(os.environ.get("DT_GRID_STREAMS", "3"))))
         side = _side_streams(device, n_streams)          # kept across calls: a handle keeps one workspace per stream
         results = [None] * len(students)
@@ -114,6 +117,8 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
         # for an idle chip and lose more to the interference than the students gain from the overlap.  The students then
         # share the chip among themselves on the side streams.
         t_groups = sample_grid_groups(handles[0], table, 0, count, T, scales, H, H)
+        # Wasserstein coordinate table of every row (E > 1000 only): the sample's table, repeated per row block
+        row_sets = [None if index_row is None else index_row.repeat(g.traj.shape[1] // count).to(device) for g in t_groups]
         ready = torch.cuda.Event()       # the teacher's trajectories (and every upload above) are complete
         ready.record(main)
 
@@ -128,7 +133,7 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
                             i = order.pop(0)
                         s_groups = sample_grid_groups(handles[1 + i], table, 0, count, T, scales, H, H, throttle=len(side) > 1)
                         parts = []
-                        for (_, X), (_, Y), rows in zip(t_groups, s_groups, row_sets):
+                        for (_, X, _), (_, Y, _), rows in zip(t_groups, s_groups, row_sets):
                             sums = engine.device_metric_sums(X, Y)                       # [G*S, n, 4]
                             w1 = engine.device_wasserstein(X, Y, index, rows)            # [G*S, n]
                             parts.append(torch.cat([sums.reshape(X.shape[1], -1), w1], dim=1))
@@ -157,10 +162,9 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
     per_row = np.stack([vals[k] for k in engine.SCALAR_KEYS], axis=1).reshape(n_sf, n_rows, K)
     out = np.empty((n_sf, len(scales), count, K))
     base = 0
-    for group, X in t_groups:
-        G = X.shape[1] // count
-        for g, gs in enumerate(group):
-            lo = base + (g * count if G > 1 else 0)
+    for group, X, block_of in t_groups:
+        for gs, blk in zip(group, block_of):
+            lo = base + blk * count
             for j, s in enumerate(scales):
                 if s == gs or (s is None and gs is None):
                     out[:, j] = per_row[:, lo: lo + count]

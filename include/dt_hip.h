@@ -27,8 +27,10 @@ extern "C" {
 #endif
 
 /* 2: time-bias rows carry enc1.conv2's class-bias columns (dt_unet_time_bias_stride), launch kind 5 and the 256 x 64 tile
- * in the conv-choice hooks; the exported symbols are those of version 1 */
-#define DT_ABI_VERSION 2
+ * in the conv-choice hooks; the exported symbols are those of version 1
+ * 3: + dt_unet_forward_mixed / dt_sample_trajectory_mixed (single-pass and CFG images in one batch); dt_sample_trajectory
+ *    accepts eps_scratch_dev == NULL */
+#define DT_ABI_VERSION 3
 
 enum {
   DT_OK = 0,
@@ -109,6 +111,15 @@ int dt_unet_forward(const dt_unet *h, const float *x_dev, int B, int n_pass, int
                     const float *tb_dev, int tb_div, float *eps_dev,
                     void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* Mixed batch: the first B_single images take ONE pass (the reference's branch for guidance_scale None / <= 1,
+ * analysis/trajectory_engine.py:83), the remaining B - B_single take the two CFG passes (:65-80).  One forward covers
+ * 2B - B_single rows laid out [pass 0 of all B images | pass 1 of images B_single .. B-1]; eps has that many rows; batch
+ * row r uses time-bias row r / tb_div, where tb_div must divide B_single and 2B - B_single.  Same kernels as
+ * dt_unet_forward: the single-pass images ride in the CFG images' launches instead of a launch sequence of their own. */
+int dt_unet_forward_mixed(const dt_unet *h, const float *x_dev, int B, int B_single, int H, int W,
+                          const float *tb_dev, int tb_div, float *eps_dev,
+                          void *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Optional: measure (HIP events, synchronises the stream) every admissible tile / tap-split of every
  * convolution launch of a forward with batch_total = n_pass*B rows and remember the fastest per layer;
  * later dt_unet_forward / dt_sample_trajectory calls with the same (batch_total, H, W) use them.
@@ -182,6 +193,16 @@ int dt_sample_trajectory(const dt_unet *h, int rule, int B, int n_pass, int H, i
                          const float *z_dev, const int32_t *z_row_dev, const int64_t *z_shift_host,
                          const float *w_dev, float w_scalar, float *traj_dev, float *eps_scratch_dev,
                          void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* The same loop for a mixed batch (see dt_unet_forward_mixed): images [0, B_single) are advanced with the single-pass
+ * prediction (eps = model(x, t)), images [B_single, B) with eps_u + w[b] (eps_c - eps_u).  tb_dev holds
+ * n_steps * (2B - B_single) / tb_div rows in (step, row group) order; w_dev[B] (entries below B_single are ignored).
+ * This is how one launch sequence serves every guidance scale of compare_trajectories (trajectory_engine.py:142-164). */
+int dt_sample_trajectory_mixed(const dt_unet *h, int rule, int B, int B_single, int H, int W, int n_steps,
+                               const float *tb_dev, int tb_div, const float *coef_host, const int32_t *has_noise_host,
+                               const float *z_dev, const int32_t *z_row_dev, const int64_t *z_shift_host,
+                               const float *w_dev, float *traj_dev, void *workspace_dev, size_t workspace_bytes,
+                               void *stream);
 
 /* ---------------------------------------------------------------- metrics ---
  * Replaces the reductions of analysis/metrics/trajectory_metrics.py:55-231 and

@@ -806,3 +806,83 @@ def test_split_k_is_deterministic_under_load(gpu_models):
         stop.set()
         t.join()
     h.set_precision(_hip.PREC_AUTO)
+
+
+# ------------------------------------------------------------------ round 3: odd chunk counts, mixed batches
+@pytest.mark.parametrize("sf", [0.3, 0.8])
+def test_multi_chunk_kernels_on_odd_chunk_counts(gpu_models, sf):
+    """Layers whose padded channel count is an ODD number of 16-channel chunks (48 / 80: size factor 0.3; 112 / 208: 0.8)
+    through the kernels that multiply 2 or 4 chunks per step (prec 4, K split across waves: prec 5) and through channel
+    splits: the weight packs carry zero chunks up to a multiple of four and the activation loads of the chunks past the
+    layer's own are replaced by zeros (ConvParams::ccw)."""
+    m = gpu_models(sf)
+    h = engine.UNetHandle.for_module(m)
+    B = 23
+    x = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(11)).to(DEV)
+    tb = h.time_bias([17, 17], [_hip.COND_ZERO, _hip.COND_ONE])
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = unet_ref.unet_forward(sd, x[:3].cpu(), torch.full((3,), 17), torch.ones(3, 1)).numpy()
+    tried = 0
+    for block in range(8):
+        for slot in (1, 2):
+            for prec, bm, bn, sp, fuse in [(4, 128, 64, 1, 0), (4, 64, 64, 1, 1), (4, 256, 64, 1, 0), (4, 128, 128, 1, 1), (4, 64, 64, 2, 0),
+                                           (5, 64, 64, 1, 0), (5, 64, 64, 1, 1), (5, 128, 64, 1, 1), (5, 128, 64, 2, 0), (5, 64, 128, 1, 1),
+                                           (3, 64, 64, 2, 0), (3, 128, 64, 4, 0)]:
+                h.set_precision(_hip.PREC_AUTO)
+                try:
+                    h.set_conv_choice(2 * B, 16, 16, block, slot, bm, bn, sp, prec, fuse if slot == 2 else 0)
+                except _hip.HipLibraryError:
+                    continue
+                kinds = [c for c in h.conv_choices(2 * B, 16, 16) if c[0] == engine.BLOCK_NAMES[block] and c[1] == ("conv1", "conv2")[slot - 1]]
+                got = h.forward(x, tb, 2, B, tune=False)
+                assert_close(got[B:B + 3].cpu().numpy(), want, what=f"sf {sf} block {block} slot {slot} {prec}/{bm}x{bn}/s{sp}/f{fuse} -> {kinds}")
+                tried += 1
+    h.set_precision(_hip.PREC_AUTO)
+    assert tried >= 100, tried
+
+
+@pytest.mark.parametrize("sf", [0.2, 1.0])
+def test_mixed_batch_forward_matches_oracle(gpu_models, sf):
+    """dt_unet_forward_mixed: images [0, b_single) take one pass (cond None), the others the two CFG passes (cond 0 / 1);
+    every row against the oracle forward of its (image, t, cond)."""
+    m = gpu_models(sf)
+    h = engine.UNetHandle.for_module(m)
+    S, G = 2, 3                                   # row blocks of S images: 1 single-pass block, G CFG blocks
+    B, b_single = (1 + G) * S, S
+    x = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(3)).to(DEV)
+    t = 23
+    tb = h.time_bias([t] * (1 + 2 * G), [_hip.COND_NONE] + [_hip.COND_ZERO] * G + [_hip.COND_ONE] * G)
+    got = h.forward_mixed(x, tb, b_single, S, tune=False).cpu().numpy()
+    assert got.shape[0] == 2 * B - b_single
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    xc = x.cpu()
+    with torch.no_grad():
+        tt = lambda n: torch.full((n,), t)
+        want = torch.cat([unet_ref.unet_forward(sd, xc[:S], tt(S), None),
+                          unet_ref.unet_forward(sd, xc[S:], tt(B - S), torch.zeros(B - S, 1)),
+                          unet_ref.unet_forward(sd, xc[S:], tt(B - S), torch.ones(B - S, 1))]).numpy()
+    assert_close(got, want, what=f"mixed forward sf {sf}")
+
+
+def test_mixed_batch_sampler_matches_separate_plans(gpu_models, monkeypatch):
+    """One mixed launch sequence (single-pass samples riding in the CFG samples' launches) gives the trajectories of the
+    two separate launch sequences: same kernels, same arithmetic per row, other launch shapes (fp32 re-association only)."""
+    from distillation_trajectories_amd.analysis.trajectory_engine import sample_grid
+    from distillation_trajectories_amd.synthetic import noise_table
+    m = gpu_models(0.5)
+    h = engine.UNetHandle.for_module(m)
+    S, T = 5, 12
+    table = noise_table(42, S + T - 1, (1, 3, 16, 16)).reshape(S + T - 1, -1).to(DEV)
+    scales = [1.0, None, 3.0, 7.5]
+    monkeypatch.setenv("DT_GRID_MERGE", "0")
+    sep = {gs: v.clone() for gs, v in sample_grid(h, table, 0, S, T, scales, 16, 16).items()}
+    monkeypatch.setenv("DT_GRID_MERGE", "1")
+    mix = sample_grid(h, table, 0, S, T, scales, 16, 16)
+    assert set(mix) == set(sep)
+    for gs in scales:
+        assert mix[gs].shape == sep[gs].shape == (T + 1, S, 768)
+        scale = float(sep[gs].abs().max())
+        err = float((mix[gs] - sep[gs]).abs().max()) / scale
+        assert err < 2e-5, (gs, err)
+    assert torch.equal(mix[1.0], mix[None])           # one row block serves every scale without the CFG branch
