@@ -68,8 +68,8 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
 
     The teacher runs once per CFG plan on the current stream, alone (see the note at its launch).  The students are
     independent of each other, so they then share the chip on ``streams`` side streams (default DT_GRID_STREAMS or 3),
-    one host thread each, largest model first, the next model handed to whichever thread's stream has drained furthest:
-    the small students, whose launches cannot fill 256 CUs, overlap the bigger ones.  Every device result stays in HBM until ONE device-to-host copy at the end; the scalar
+    one host thread each, assigned longest-first by a static cost model: the small students, whose launches cannot fill
+    256 CUs, overlap the bigger ones.  Every device result stays in HBM until ONE device-to-host copy at the end; the scalar
     post-transforms then run once, vectorised over every (student, scale, sample) row.
     ``table``: the device noise table [count+T-1, E] when the caller already holds it (bench.py).
     """
@@ -110,8 +110,17 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
         side = _side_streams(device, n_streams)          # kept across calls: a handle keeps one workspace per stream
         results = [None] * len(students)
         errors = []
-        order = sorted(range(len(students)), key=lambda i: -sum(p.numel() for p in students[i].parameters()))
-        lock = threading.Lock()
+        # Static longest-first assignment of the students to the side streams (cost model from the per-model timings in
+        # tools/config2_breakdown.py: ~10 ms of launch-bound work per loop + time proportional to the parameter count).
+        # Static, because a handle keeps one workspace per stream it has run on: with models handed out by arrival the
+        # (model, stream) pairs changed from step to step and every new pair allocated a workspace mid-step (a 20 ms
+        # stall of all streams in the kernel trace).
+        cost = [10.0 + 4.5e-6 * sum(p.numel() for p in m.parameters()) for m in students]
+        queues, load = [[] for _ in range(n_streams)], [0.0] * n_streams
+        for i in sorted(range(len(students)), key=lambda i: -cost[i]):
+            k = min(range(n_streams), key=lambda q: load[q])
+            queues[k].append(i)
+            load[k] += cost[i]
         # The teacher runs FIRST, alone: measured on MI355X (configs[2], same box, alternating runs) its loop sharing the
         # chip with the students' small launches costs 13 % of the step (469-482 vs 418-428 ms) -- its big tiles are tuned
         # for an idle chip and lose more to the interference than the students gain from the overlap.  The students then
@@ -126,11 +135,7 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
             try:
                 with torch.cuda.device(device), torch.cuda.stream(side[k]):
                     side[k].wait_event(ready)
-                    while True:
-                        with lock:
-                            if not order:
-                                return
-                            i = order.pop(0)
+                    for i in queues[k]:
                         s_groups = sample_grid_groups(handles[1 + i], table, 0, count, T, scales, H, H, throttle=len(side) > 1)
                         parts = []
                         for (_, X, _), (_, Y, _), rows in zip(t_groups, s_groups, row_sets):
@@ -142,6 +147,7 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
                 errors.append(e)
         if streams == 1:                 # serial mode (per-kernel profiling): everything on the caller's stream, in order
             side = [main]
+            queues = [sorted(range(len(students)), key=lambda i: -cost[i])]
             worker(0)
             threads = []
         else:

@@ -18,12 +18,12 @@ S, T, H, C = int(os.environ.get("DT_C2_S", "64")), 50, 16, 3
 cfg = Config(); cfg.image_size, cfg.timesteps = H, T
 table = noise_table(42, S + T - 1, (1, C, H, H)).reshape(S + T - 1, -1).to(dev)
 sizes = [float(v) for v in os.environ.get("DT_C2_SIZES", ",".join(map(str, bench.SIZES))).split(",")]
-tot = [0.0, 0.0]
+tot = [0.0, 0.0, 0.0]
 for sf in sizes:
     m = make_model(DiffusionUNet, cfg, sf).to(dev)
     h = engine.UNetHandle.for_module(m)
     row = []
-    for k, scales in enumerate(([1.0], [3.0, 7.0, 20.0])):
+    for k, scales in enumerate(([1.0], [3.0, 7.0, 20.0], [1.0, 3.0, 7.0, 20.0])):
         fn = lambda: sample_grid_groups(h, table, 0, S, T, scales, H, H)
         fn(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -31,13 +31,13 @@ for sf in sizes:
             fn()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 3 * 1e3
-        rows = S if k == 0 else 2 * 3 * S
+        rows = (S, 6 * S, 7 * S)[k]
         tf = 2 * MACS[sf] * rows * (T - 1) / (ms * 1e-3) / 1e12
         row.append((ms, tf))
         tot[k] += ms
     print(f"sf {sf:4}: plain B={S} {row[0][0]:7.2f} ms ({row[0][0] / 49 * 1e3:6.0f} us/fwd, {row[0][1]:6.1f} TF/s)   guided B={3 * S}x2 {row[1][0]:7.2f} ms "
-          f"({row[1][0] / 49 * 1e3:6.0f} us/fwd, {row[1][1]:6.1f} TF/s)", flush=True)
+          f"({row[1][0] / 49 * 1e3:6.0f} us/fwd, {row[1][1]:6.1f} TF/s)   mixed {7 * S} rows {row[2][0]:7.2f} ms ({row[2][0] / 49 * 1e3:6.0f} us/fwd, {row[2][1]:6.1f} TF/s)", flush=True)
     if os.environ.get("DT_C2_PLAN"):
-        for bt in (S, 6 * S):
+        for bt in (7 * S,):
             print("   ", bt, [(c[0], c[1], c[2], c[3], c[4], c[5]) for c in h.conv_choices(bt, H, H)])
-print(f"sum plain {tot[0]:.1f} ms, guided {tot[1]:.1f} ms (teacher = sf 1.0 runs twice in the grid: + {0:.0f})")
+print(f"sum plain {tot[0]:.1f} ms, guided {tot[1]:.1f} ms, mixed {tot[2]:.1f} ms (the teacher = sf 1.0 runs twice in the grid)")
