@@ -173,9 +173,9 @@ class PairWorkload:
             self.w_index, self.w_rows = tables.to(device), rows.to(device)
         for i, ps in enumerate(self.parts):
             for h, (lo, hi) in ps:
-                # tile / split / arithmetic autotuning happens here, one launch shape at a time on an idle GPU
+                # the launch plan of the shape is settled here (committed table; timing only with DT_AUTOTUNE=1), on an idle GPU
                 tb = h.time_bias_general(self.tb_t[:2], self.tb_cond[:2], self.tb_present[:2], 2)
-                h.forward(self.x_T[lo:hi].reshape(hi - lo, C, H, H), tb, 2, hi - lo, tune=True)
+                h.forward(self.x_T[lo:hi].reshape(hi - lo, C, H, H), tb, 2, hi - lo)
         torch.cuda.synchronize()
         self.choices = None
         self.concurrent = concurrent

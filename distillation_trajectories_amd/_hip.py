@@ -38,6 +38,7 @@ SIGNATURES = {
     "dt_unet_conv_choice": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int),
                                     POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "dt_unet_set_conv_choice": (c_int, [c_void_p] + [c_int] * 10),
+    "dt_unet_declare_shape": (c_int, [c_void_p] + [c_int] * 5),
     "dt_unet_set_precision": (c_int, [c_void_p, c_int]),
     "dt_unet_set_head_fusion": (c_int, [c_void_p, c_int]),
     "dt_unet_time_conv": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -102,6 +102,7 @@ struct BlockW {
 // one forward shape, filled in by dt_unet_autotune; absent shapes use heuristic_choice
 struct TunedShape {
   int Bt, H, W;
+  int imgs, single;   // how the Bt rows split into images (see ShapeInfo): enc1's launches run over the images
   ConvChoice c[kBlocks][3];
 };
 
@@ -190,9 +191,9 @@ void drop_graphs(dt_unet *u) {
   u->graphs.clear();
 }
 
-const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W) {
+const TunedShape *find_tuned(const dt_unet *u, int Bt, int H, int W, int imgs, int single) {
   for (const TunedShape &t : u->tuned)
-    if (t.Bt == Bt && t.H == H && t.W == W) return &t;
+    if (t.Bt == Bt && t.H == H && t.W == W && t.imgs == imgs && t.single == single) return &t;
   return nullptr;
 }
 
@@ -359,7 +360,7 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
   note_shape(u, Bt, H, W, B, B_single);
   const Plan pl = make_plan(u, Bt, H, W);
   if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
-  const TunedShape *tuned = find_tuned(u, Bt, H, W);
+  const TunedShape *tuned = find_tuned(u, Bt, H, W, B, B_single);
   int st = DT_OK;
   const float *cur = x;                     // enc1 reads the NCHW image itself (first-layer kernel, skip in conv2's epilogue)
   for (int j = 0; j < kBlocks; ++j) {
@@ -574,6 +575,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
   DT_HIP_TRY(hipEventCreate(&e1));
   TunedShape t{};
   t.Bt = batch_total; t.H = H; t.W = W;
+  shape_images(h, batch_total, H, W, t.imgs, t.single);   // the split of the last forward with this row count
   const float *tb = h->slab;   // any readable floats: only timing matters here
   int st = DT_OK;
   {   // The clocks of an idle GPU take tens of milliseconds of load to settle (the same launch measures 15 % slower
@@ -693,7 +695,7 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace,
   (void)hipEventDestroy(e1);
   if (st != DT_OK) return st;
   for (TunedShape &old : h->tuned)
-    if (old.Bt == t.Bt && old.H == t.H && old.W == t.W) { old = t; drop_graphs(h); return DT_OK; }
+    if (old.Bt == t.Bt && old.H == t.H && old.W == t.W && old.imgs == t.imgs && old.single == t.single) { old = t; drop_graphs(h); return DT_OK; }
   h->tuned.push_back(t);
   drop_graphs(h);
   return DT_OK;
@@ -756,7 +758,9 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
   if (!h || !bm || !bn || !splits || !prec || !tuned) return DT_E_NULL;
   if (block < 0 || block >= kBlocks || slot < 0 || slot > 2 || H % 16 || W % 16 || batch_total < 1) return DT_E_ARG;
   const Plan pl = make_plan(h, batch_total, H, W);
-  const TunedShape *t = find_tuned(h, batch_total, H, W);
+  int imgs = 0, single = 0;
+  shape_images(h, batch_total, H, W, imgs, single);
+  const TunedShape *t = find_tuned(h, batch_total, H, W, imgs, single);
   ConvParams p;
   float dummy = 0.f;
   if (!conv_slot(h, block, slot, &dummy, &dummy, pl, batch_total, &dummy, 1, t ? &t->c[block][slot] : nullptr, p)) {
@@ -773,6 +777,14 @@ int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int blo
   return DT_OK;
 }
 
+int dt_unet_declare_shape(dt_unet *h, int batch_total, int H, int W, int images, int single) {
+  if (!h) return DT_E_NULL;
+  if (batch_total < 1 || H < 16 || W < 16 || H % 16 || W % 16 || images < 1 || single < 0 || single >= images) return DT_E_ARG;
+  if (batch_total != images && batch_total != 2 * images - single && (single || batch_total % images)) return DT_E_ARG;
+  note_shape(h, batch_total, H, W, images, single);
+  return DT_OK;
+}
+
 int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block, int slot, int bm, int bn, int splits,
                             int prec, int fuse) {
   if (!h) return DT_E_NULL;
@@ -786,11 +798,13 @@ int dt_unet_set_conv_choice(dt_unet *h, int batch_total, int H, int W, int block
   if (h->blk[block].n_p % bn) return DT_E_ARG;
   const Plan pl = make_plan(h, batch_total, H, W);
   TunedShape *t = nullptr;
+  int imgs = 0, single = 0;
+  shape_images(h, batch_total, H, W, imgs, single);
   for (TunedShape &old : h->tuned)
-    if (old.Bt == batch_total && old.H == H && old.W == W) t = &old;
+    if (old.Bt == batch_total && old.H == H && old.W == W && old.imgs == imgs && old.single == single) t = &old;
   if (!t) {   // start from what an untuned forward would launch
     TunedShape fresh{};
-    fresh.Bt = batch_total; fresh.H = H; fresh.W = W;
+    fresh.Bt = batch_total; fresh.H = H; fresh.W = W; fresh.imgs = imgs; fresh.single = single;
     float dummy = 0.f;
     for (int j = 0; j < kBlocks; ++j)
       for (int sl = 0; sl < 3; ++sl) {

@@ -40,19 +40,41 @@ def sinusoid_frequencies(dim):
     return torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1 + 1e-8)))
 
 
-class _TuneCache:
-    """Optional on-disk record of autotuned launch plans (env DT_TUNE_CACHE = a JSON file).  The autotuner's picks between
-    near-equal candidates differ from run to run, which changes results at fp32-rounding level and makes profiler passes
-    of 'the same command' launch different kernels; with a cache every process replays the plan the first one measured."""
+PLAN_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "gfx950.json")
+
+
+class _Plans:
+    """Launch plans (tile / split / kernel family per convolution of a forward shape).
+
+    Results must not depend on which process runs them: by default a shape's plan is a pure function of the model and the
+    shape -- the entry of the COMMITTED per-arch table ``plans/gfx950.json`` (measured once with
+    ``tools/make_plan_table.py`` for the BASELINE shapes) or, for shapes the table does not hold, the library's
+    deterministic heuristic.  Timing candidates in the process (``dt_unet_autotune``: its picks between near-equal
+    candidates differ from run to run, which changes results at fp32-rounding level) is opt-in: ``DT_AUTOTUNE=1``, or
+    ``tune=True`` on a call; ``DT_TUNE_CACHE=file`` then records what was measured so that later processes replay it.
+    """
+    _table = None
+    _lock = None
+
+    @classmethod
+    def table(cls):
+        if cls._table is None:
+            import json
+            try:
+                with open(PLAN_TABLE) as f:
+                    cls._table = json.load(f).get("plans", {})
+            except (OSError, ValueError):
+                cls._table = {}
+        return cls._table
 
     @staticmethod
-    def path():
+    def cache_path():
         return os.environ.get("DT_TUNE_CACHE") or None
 
     @staticmethod
-    def load():
+    def cache_load():
         import json
-        p = _TuneCache.path()
+        p = _Plans.cache_path()
         if not p:
             return None
         try:
@@ -62,15 +84,25 @@ class _TuneCache:
             return {}
 
     @staticmethod
-    def store(key, plan):
+    def cache_store(key, plan):
+        """Read-modify-replace under an exclusive lock file (several ranks may tune at once)."""
+        import fcntl
         import json
-        p = _TuneCache.path()
-        cache = _TuneCache.load() or {}
-        cache[key] = plan
-        tmp = f"{p}.{os.getpid()}.tmp"
-        with open(tmp, "w") as f:
-            json.dump(cache, f)
-        os.replace(tmp, p)
+        p = _Plans.cache_path()
+        with open(p + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            cache = _Plans.cache_load() or {}
+            cache[key] = plan
+            tmp = f"{p}.{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                json.dump(cache, f)
+            os.replace(tmp, p)
+
+    @staticmethod
+    def digest(plan):
+        import hashlib
+        import json
+        return hashlib.sha1(json.dumps(plan, sort_keys=True).encode()).hexdigest()[:10]
 
 
 class UNetHandle:
@@ -102,9 +134,11 @@ class UNetHandle:
         self.tb_stride = self.lib.dt_unet_time_bias_stride(self.h)
         mode = os.environ.get("DT_PRECISION", "auto")
         check(self.lib.dt_unet_set_precision(self.h, {"fp32": 0, "split-bf16": 1, "auto": 2}[mode]), "dt_unet_set_precision")
+        self._mode = mode
+        self._shared_enc1 = os.environ.get("DT_NO_SHARED_ENC1") is None      # read by dt_unet_create
         self._ws = {}
         self._consts = {}
-        self._tuned = set()
+        self._plans = {}              # (rows, H, W, images, single-pass images) -> plan id ("table:<sha1>", "tuned:<sha1>", "heuristic", "pinned")
 
     def __del__(self):
         try:
@@ -156,47 +190,89 @@ class UNetHandle:
     def set_precision(self, mode):
         """PREC_FP32 (exact fp32 MFMA), PREC_SPLIT_BF16 (3-plane bf16 split, 6 products) or PREC_AUTO."""
         check(self.lib.dt_unet_set_precision(self.h, int(mode)), "dt_unet_set_precision")
-        self._tuned.clear()
+        self._mode = {0: "fp32", 1: "split-bf16", 2: "auto"}[int(mode)]
+        self._plans.clear()               # the library drops its tuned shapes too: choices are per arithmetic mode
 
     def set_head_fusion(self, on):
         """Test hook (dt_unet_set_head_fusion): off = separate head launch, dec1's output is materialised."""
         check(self.lib.dt_unet_set_head_fusion(self.h, int(bool(on))), "dt_unet_set_head_fusion")
 
-    def autotune(self, batch_total, H, W):
-        """Measure tile / tap-split candidates for this forward shape once and keep the fastest (dt_unet_autotune)."""
-        key = (batch_total, H, W)
-        if key in self._tuned:
-            return
-        cache_key = f"{self.channels}:{self.temb_dim}:{','.join(map(str, self.dims))}:{batch_total}x{H}x{W}"
-        cache = _TuneCache.load()
-        if cache is not None and cache_key in cache:
-            # a recorded plan (DT_TUNE_CACHE=file): every process / profiler pass then launches the same kernels
-            for block, slot, bm, bn, sp, prec, fuse in cache[cache_key]:
-                check(self.lib.dt_unet_set_conv_choice(self.h, batch_total, H, W, block, slot, bm, bn, sp, prec, fuse),
-                      "dt_unet_set_conv_choice")
-            self._tuned.add(key)
-            return
-        ws = self.workspace(batch_total, H, W)
+    @property
+    def _tuned(self):
+        """{(rows, H, W)} of the shapes that run a table / measured / pinned plan (not the bare heuristic)."""
+        return {k[:3] for k, v in self._plans.items() if v != "heuristic"}
+
+    def plan_key(self, rows, H, W, imgs, single):
+        return (f"abi{_hip.ABI_VERSION}|gfx950|prec={self._mode}|enc1={'shared' if self._shared_enc1 else 'per-pass'}|C{self.channels}"
+                f"|D{self.temb_dim}|{','.join(map(str, self.dims))}|{rows}x{H}x{W}|{imgs}/{single}")
+
+    def _read_plan(self, rows, H, W):
+        plan = []
+        for j in range(8):
+            for slot in range(3):
+                bm, bn, sp, pr, tu = c_int(), c_int(), c_int(), c_int(), c_int()
+                check(self.lib.dt_unet_conv_choice(self.h, rows, H, W, j, slot, ctypes.byref(bm), ctypes.byref(bn),
+                                                   ctypes.byref(sp), ctypes.byref(pr), ctypes.byref(tu)), "dt_unet_conv_choice")
+                if bm.value:
+                    plan.append([j, slot, bm.value, bn.value, sp.value, pr.value & 7, 1 if pr.value & 8 else 0])
+        return plan
+
+    def _apply_plan(self, rows, H, W, plan):
+        """Pin every launch of a recorded plan; an entry this build no longer admits (or that contradicts the handle's
+        arithmetic mode) is skipped, which leaves that slot on the heuristic."""
+        ok = True
+        for block, slot, bm, bn, sp, prec, fuse in plan:
+            if (self._mode == "fp32") != (prec == 0) and self._mode != "auto":
+                ok = False
+                continue
+            if self.lib.dt_unet_set_conv_choice(self.h, rows, H, W, block, slot, bm, bn, sp, prec, fuse) != 0:
+                ok = False
+        return ok
+
+    def ensure_plan(self, rows, H, W, imgs, single, tune=None, warm=None):
+        """Settle the launch plan of a forward shape once (see ``_Plans``).  ``warm`` runs one forward of the shape
+        (real activations in the workspace) before candidates are timed.  Returns the plan id."""
+        key = (rows, H, W, imgs, single)
+        have = self._plans.get(key)
+        if have is not None and not (tune is True and not have.startswith(("tuned", "pinned"))):
+            return have
+        check(self.lib.dt_unet_declare_shape(self.h, rows, H, W, imgs, single), "dt_unet_declare_shape")
+        if tune is False:
+            self._plans[key] = "heuristic"
+            return "heuristic"
+        pkey = self.plan_key(rows, H, W, imgs, single)
+        if tune is not True:
+            for source, entries in (("table", _Plans.table()), ("cache", _Plans.cache_load() or {})):
+                plan = entries.get(pkey)
+                if plan and self._apply_plan(rows, H, W, plan):
+                    self._plans[key] = f"{source}:{_Plans.digest(plan)}"
+                    return self._plans[key]
+        measure = tune is True or (os.environ.get("DT_AUTOTUNE", "0") == "1" and rows * H * W >= AUTOTUNE_MIN_ROWS)
+        if not measure:
+            self._plans[key] = "heuristic"
+            return "heuristic"
+        if warm is not None:
+            warm()
+        ws = self.workspace(rows, H, W)
         with torch.cuda.device(self.device):
-            check(self.lib.dt_unet_autotune(self.h, batch_total, H, W, ptr(ws), c_size_t(ws.numel()), stream_ptr()),
-                  "dt_unet_autotune")
-        self._tuned.add(key)
-        if cache is not None:
-            plan = []
-            for j in range(8):
-                for slot in range(3):
-                    bm, bn, sp, pr, tu = c_int(), c_int(), c_int(), c_int(), c_int()
-                    check(self.lib.dt_unet_conv_choice(self.h, batch_total, H, W, j, slot, ctypes.byref(bm), ctypes.byref(bn),
-                                                       ctypes.byref(sp), ctypes.byref(pr), ctypes.byref(tu)), "dt_unet_conv_choice")
-                    if bm.value:
-                        plan.append([j, slot, bm.value, bn.value, sp.value, pr.value & 7, 1 if pr.value & 8 else 0])
-            _TuneCache.store(cache_key, plan)
+            check(self.lib.dt_unet_autotune(self.h, rows, H, W, ptr(ws), c_size_t(ws.numel()), stream_ptr()), "dt_unet_autotune")
+        plan = self._read_plan(rows, H, W)
+        self._plans[key] = f"tuned:{_Plans.digest(plan)}"
+        if _Plans.cache_path():
+            _Plans.cache_store(pkey, plan)
+        return self._plans[key]
+
+    def plan_ids(self):
+        """{"rowsxHxW imgs/single": plan id} of every shape this handle has run (bench.py prints it)."""
+        return {f"{k[0]}x{k[1]}x{k[2]} {k[3]}/{k[4]}": v for k, v in sorted(self._plans.items())}
 
     def set_conv_choice(self, batch_total, H, W, block, slot, bm, bn, splits=1, prec=1, fuse=0):
         """Pin one convolution's launch choice for this forward shape (dt_unet_set_conv_choice)."""
         check(self.lib.dt_unet_set_conv_choice(self.h, batch_total, H, W, block, slot, bm, bn, splits, prec, fuse),
               "dt_unet_set_conv_choice")
-        self._tuned.add((batch_total, H, W))
+        for k in [k for k in self._plans if k[:3] == (batch_total, H, W)]:
+            self._plans[k] = "pinned"
+        self._pinned = getattr(self, "_pinned", set()) | {(batch_total, H, W)}
 
     def conv_choices(self, batch_total, H, W):
         """[(block, slot, bm, bn, splits, tuned)] for reporting."""
@@ -251,11 +327,15 @@ class UNetHandle:
             with torch.cuda.device(self.device):
                 check(self.lib.dt_unet_forward(self.h, ptr(x), B, n_pass, H, W, ptr(tb), tb_div, ptr(eps), ptr(ws),
                                                c_size_t(ws.numel()), stream_ptr()), "dt_unet_forward")
-        if self._wants_tuning(n_pass * B, H, W, tune):
-            run()                                  # real activations in the workspace for the timing runs
-            self.autotune(n_pass * B, H, W)
+        self._settle(n_pass * B, H, W, B, 0, tune, run)
         run()
         return eps
+
+    def _settle(self, rows, H, W, imgs, single, tune, warm):
+        if (rows, H, W) in getattr(self, "_pinned", ()):      # launches pinned by hand (tests, tools): leave them alone
+            self._plans.setdefault((rows, H, W, imgs, single), "pinned")
+            return
+        self.ensure_plan(rows, H, W, imgs, single, tune, warm)
 
     def forward_mixed(self, x, tb, b_single, tb_div, tune=None):
         """eps[2B - b_single, C, H, W] of a mixed batch (dt_unet_forward_mixed): images [0, b_single) take one pass,
@@ -271,9 +351,7 @@ class UNetHandle:
             with torch.cuda.device(self.device):
                 check(self.lib.dt_unet_forward_mixed(self.h, ptr(x), B, b_single, H, W, ptr(tb), tb_div, ptr(eps), ptr(ws),
                                                      c_size_t(ws.numel()), stream_ptr()), "dt_unet_forward_mixed")
-        if self._wants_tuning(rows, H, W, tune):
-            run()
-            self.autotune(rows, H, W)
+        self._settle(rows, H, W, B, b_single, tune, run)
         run()
         return eps
 
@@ -288,22 +366,14 @@ class UNetHandle:
         noise_c = (c_int32 * n_steps)(*[int(bool(v)) for v in has_noise])
         shift_c = (c_int64 * n_steps)(*[int(v) for v in (z_shift if z_shift is not None else [0] * n_steps)])
         ws = self.workspace(rows, H, W)
-        if n_steps and self._wants_tuning(rows, H, W, None):
+        if n_steps and (rows, H, W, B, b_single) not in self._plans:
             per_step = rows // tb_div
-            self.forward_mixed(traj[0].reshape(B, self.channels, H, W), tb[:per_step].contiguous(), b_single, tb_div, tune=True)
+            self.forward_mixed(traj[0].reshape(B, self.channels, H, W), tb[:per_step].contiguous(), b_single, tb_div)
         with torch.cuda.device(self.device):
             check(self.lib.dt_sample_trajectory_mixed(self.h, rule, B, b_single, H, W, n_steps, ptr(tb), tb_div, coef_c, noise_c,
                                                       ptr(z), ptr(z_row), shift_c, ptr(w), ptr(traj), ptr(ws),
                                                       c_size_t(ws.numel()), stream_ptr()), "dt_sample_trajectory_mixed")
         return traj
-
-    def _wants_tuning(self, batch_total, H, W, tune):
-        """Autotune big shapes once (>= 16k GEMM rows at full resolution) unless DT_AUTOTUNE=0."""
-        if (batch_total, H, W) in self._tuned:
-            return False
-        if tune is None:
-            tune = os.environ.get("DT_AUTOTUNE", "1") != "0" and batch_total * H * W >= AUTOTUNE_MIN_ROWS
-        return bool(tune)
 
     def debug_activation(self, batch_total, H, W, which):
         """NHWC view [Bt,h,w,cp] of block ``which``'s output inside the workspace of the last forward."""
@@ -325,8 +395,8 @@ class UNetHandle:
         noise_c = (c_int32 * n_steps)(*[int(bool(v)) for v in has_noise])
         shift_c = (c_int64 * n_steps)(*[int(v) for v in (z_shift if z_shift is not None else [0] * n_steps)])
         ws = self.workspace(n_pass * B, H, W)
-        if n_steps and self._wants_tuning(n_pass * B, H, W, None):
-            self.forward(traj[0].reshape(B, self.channels, H, W), tb[:n_pass].contiguous(), n_pass, B, tune=True)
+        if n_steps and (n_pass * B, H, W, B, 0) not in self._plans:
+            self.forward(traj[0].reshape(B, self.channels, H, W), tb[:n_pass].contiguous(), n_pass, B)
         with torch.cuda.device(self.device):
             check(self.lib.dt_sample_trajectory(self.h, rule, B, n_pass, H, W, n_steps, ptr(tb), coef_c, noise_c,
                                                 ptr(z), ptr(z_row), shift_c, ptr(w), c_float(w_scalar), ptr(traj),

@@ -89,22 +89,21 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
             tables, rows = wasserstein_index_tables([42 + first_sample + s for s in range(count)], n, E)
             index, index_row = _upload(tables), rows
         handles = [engine.UNetHandle.for_module(m) for m in [teacher] + list(students)]
-        # launch-plan autotuning times kernels with events: do it before anything runs concurrently
         from .analysis.trajectory_engine import _merge_plans, uses_cfg
         n_cfg = sum(1 for gs in scales if uses_cfg(gs))
         merged = n_cfg and n_cfg < len(scales) and _merge_plans()
         plans = [] if merged else [(1, count)] + ([(2, count * n_cfg)] if n_cfg else [])
-        for h in handles:
-            if merged and h._wants_tuning((1 + 2 * n_cfg) * count, H, H, None):
+        for h in handles:             # settle every launch plan (table lookup, or timing with DT_AUTOTUNE=1) before streams share the chip
+            if merged and ((1 + 2 * n_cfg) * count, H, H, (1 + n_cfg) * count, count) not in h._plans:
                 B = (1 + n_cfg) * count
                 tb = h.time_bias([T - 1] * (1 + 2 * n_cfg), [0] * (1 + 2 * n_cfg))
                 x = table[torch.arange(B, device=device) % table.shape[0]]            # real noise: zeros clock differently
-                h.forward_mixed(x.reshape(B, C, H, H), tb, count, count, tune=True)
+                h.forward_mixed(x.reshape(B, C, H, H), tb, count, count)
             for n_pass, B in plans:
-                if B and h._wants_tuning(n_pass * B, H, H, None):
+                if B and (n_pass * B, H, H, B, 0) not in h._plans:
                     tb = h.time_bias([T - 1] * n_pass, [0] * n_pass)
                     x = table[torch.arange(B, device=device) % table.shape[0]]        # real noise: zeros clock differently
-                    h.forward(x.reshape(B, C, H, H), tb, n_pass, B, tune=True)
+                    h.forward(x.reshape(B, C, H, H), tb, n_pass, B)
         main = torch.cuda.current_stream()
         n_streams = max(1, min(len(students), streams or int(os.environ.get("DT_GRID_STREAMS", "3"))))
         side = _side_streams(device, n_streams)          # kept across calls: a handle keeps one workspace per stream

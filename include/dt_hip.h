@@ -28,8 +28,8 @@ extern "C" {
 
 /* 2: time-bias rows carry enc1.conv2's class-bias columns (dt_unet_time_bias_stride), launch kind 5 and the 256 x 64 tile
  * in the conv-choice hooks; the exported symbols are those of version 1
- * 3: + dt_unet_forward_mixed / dt_sample_trajectory_mixed (single-pass and CFG images in one batch); dt_sample_trajectory
- *    accepts eps_scratch_dev == NULL */
+ * 3: + dt_unet_forward_mixed / dt_sample_trajectory_mixed (single-pass and CFG images in one batch), dt_unet_declare_shape;
+ *    dt_sample_trajectory accepts eps_scratch_dev == NULL */
 #define DT_ABI_VERSION 3
 
 enum {
@@ -135,6 +135,11 @@ int dt_unet_autotune(dt_unet *h, int batch_total, int H, int W, void *workspace_
  * bm = 0 means the slot has no launch of its own */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
                         int *splits, int *prec, int *tuned);
+
+/* The tuning / plan hooks below are keyed by a forward's ROW count; how the rows split into images (images x passes, or a mixed
+ * batch) decides enc1's launches, which run over the images.  The hooks use the split of the last forward with that row count;
+ * this declares it beforehand (a plan applied before the first forward of a shape). */
+int dt_unet_declare_shape(dt_unet *h, int batch_total, int H, int W, int images, int single_pass_images);
 
 /* tuning / test hook: pin the launch choice of one convolution of a forward shape (the other slots keep
  * their current choice).  bm x bn in {64,128}^2, or 256 x 64 for the strip kernels (prec 3 / 4; not 128 x 128 for

@@ -320,9 +320,10 @@ def test_config2_full_size_sweep_grid(golden_r02, models):
             _check_metric_dict(got, want, 1e-4, f"grid cell sf={c['student_sf']} gs={gs}")
 
 
-def test_forward_64x64_autotuned(models):
+def test_forward_64x64_autotuned(models, monkeypatch):
     """64-pixel rows: the strip kernel cannot stage W + 1 = 65 halo pixels at the top level, so the autotuner must
-    fall back to the plain kernel there instead of failing (batch 4 x 64 x 64 = 16384 rows is where tuning starts)."""
+    fall back to the plain kernel there instead of failing (batch 4 x 64 x 64 = 16384 rows is where opt-in tuning starts)."""
+    monkeypatch.setenv("DT_AUTOTUNE", "1")
     for sf in (0.2, 1.0):
         m = copy.deepcopy(models(sf)).to(DEV)
         sd = models(sf).state_dict()
