@@ -545,6 +545,13 @@ def main():
         "ranks": ranks, "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
         "metric_check": wl.check(vals),
     }
+    # launch plans in use (engine._Plans): "table:<sha1>" = the committed per-arch table, "heuristic", "tuned:<sha1>" only with DT_AUTOTUNE=1
+    from distillation_trajectories_amd import engine as _engine
+    if args.config == 2:
+        mods = [("teacher", wl.teacher)] + [(f"sf={sf}", m) for sf, m in zip(spec["sizes"], wl.students)]
+        out["launch_plans"] = {name: _engine.UNetHandle.for_module(m).plan_ids() for name, m in mods}
+    else:
+        out["launch_plans"] = {f"sf={sf}": ps[0][0].plan_ids() for sf, ps in zip(spec["sf"], wl.parts)}
     if kernels:
         # A kernel = one __global__ template; its tile instantiations <BM,BN> are the same code on other tile sizes and
         # which of them the autotuner picks per layer varies run to run, so the roofline entry is per template.

@@ -340,8 +340,8 @@ def test_sampler_graph_replay_is_bit_exact(gpu_models, monkeypatch):
         return traj
     plain = run(torch.empty(len(idx) + 1, B, E, device=DEV)).clone()
     monkeypatch.setenv("DT_GRAPH", "1")
-    torch.cuda.synchronize()              # the handle's workspace is shared: the plain run must be done before another stream uses it
-    side = torch.cuda.Stream()
+    side = torch.cuda.Stream()            # (the handle keeps one workspace per stream: no synchronisation with the plain run needed)
+    side.wait_stream(torch.cuda.current_stream())     # x_T, z, tb were produced on the current stream
     traj = torch.empty(len(idx) + 1, B, E, device=DEV)
     with torch.cuda.stream(side):
         first = run(traj).clone()         # capture + first launch
@@ -886,3 +886,98 @@ def test_mixed_batch_sampler_matches_separate_plans(gpu_models, monkeypatch):
         err = float((mix[gs] - sep[gs]).abs().max()) / scale
         assert err < 2e-5, (gs, err)
     assert torch.equal(mix[1.0], mix[None])           # one row block serves every scale without the CFG branch
+
+
+def test_one_handle_on_two_streams_is_race_free(gpu_models):
+    """One handle, two HIP streams, launches queued concurrently from two host threads: every forward equals the serial
+    result bit for bit (a handle keeps one workspace per stream)."""
+    import threading
+    m = gpu_models(0.5)
+    h = engine.UNetHandle.for_module(m)
+    B = 32
+    g = torch.Generator().manual_seed(21)
+    xs = [torch.randn(B, 3, 16, 16, generator=g).to(DEV) for _ in range(2)]
+    tb = h.time_bias([12, 12], [_hip.COND_NONE, _hip.COND_ONE])
+    serial = [h.forward(x, tb, 2, B, tune=False).clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs, errs = [[], []], []
+
+    def worker(k):
+        try:
+            with torch.cuda.stream(streams[k]):
+                for _ in range(40):
+                    outs[k].append(h.forward(xs[k], tb, 2, B, tune=False))
+        except Exception as e:
+            errs.append(e)
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for k in range(2):
+        assert all(torch.equal(o, serial[k]) for o in outs[k]), f"stream {k}"
+
+
+_DIGEST_SCRIPT = r"""
+import hashlib, json, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import bench
+from distillation_trajectories_amd._hip import RULE_PSAMPLE
+torch.cuda.set_device(0)
+spec = bench.CONFIGS[1]
+wl = bench.PairWorkload(spec, torch.device("cuda:0"), 0, 256, concurrent=False)
+out = {}
+for i, name in enumerate(("teacher", "student")):
+    h, traj = wl.handles[i], wl.traj[i]
+    tb = h.time_bias_general(wl.tb_t, wl.tb_cond, wl.tb_present, 2 * wl.T)
+    traj[0].copy_(wl.x_T)
+    h.sample(RULE_PSAMPLE, traj, wl.H, wl.H, tb, 2, wl.coef, wl.has_noise, z=wl.z, z_shift=wl.z_shift, w_scalar=spec["guidance"])
+    out[name] = {"sha256": hashlib.sha256(traj.cpu().numpy().tobytes()).hexdigest(), "plans": h.plan_ids()}
+print("DIGEST " + json.dumps(out))
+"""
+
+
+def test_two_fresh_processes_give_identical_bits():
+    """configs[1] (teacher and student, batch 256, T = 50, two passes per step) in two fresh processes: the trajectories are
+    bit-identical, because a shape's launch plan comes from the committed table / the deterministic heuristic and nothing is
+    timed in the process (the reference's contract is seeded reproducibility, trajectory_engine.py:55-57)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("DT_AUTOTUNE", "DT_TUNE_CACHE")}
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", _DIGEST_SCRIPT, root], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")][-1]
+        runs.append(json.loads(line[7:]))
+    assert runs[0] == runs[1], runs
+    assert all(not v.startswith("tuned") for m in runs[0].values() for v in m["plans"].values()), runs[0]
+
+
+def test_plan_cache_respects_arithmetic_mode(gpu_models, tmp_path, monkeypatch):
+    """A plan measured under the auto mode must not be replayed by a handle in exact-fp32 mode (the cache key
+    lacked the mode): record a cache under auto, then PREC_FP32 still reports only fp32 kernels."""
+    cache = tmp_path / "tune.json"
+    monkeypatch.setenv("DT_TUNE_CACHE", str(cache))
+    m = gpu_models(0.5)
+    h = engine.UNetHandle.for_module(m)
+    h.set_precision(_hip.PREC_AUTO)
+    B = 40
+    x = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(2)).to(DEV)
+    tb = h.time_bias([7, 7], [_hip.COND_NONE, _hip.COND_ONE])
+    auto = h.forward(x, tb, 2, B, tune=True)
+    assert cache.exists() and h._plans[(2 * B, 16, 16, B, 0)].startswith("tuned:")
+    kinds = {c[5] for c in h.conv_choices(2 * B, 16, 16)}
+    assert any(k.startswith("split-bf16") for k in kinds), kinds
+    # a second handle of the same model replays the recorded plan (no timing) ...
+    h2 = engine.UNetHandle(m.state_dict(), torch.device(DEV))
+    again = h2.forward(x, tb, 2, B)
+    assert h2._plans[(2 * B, 16, 16, B, 0)].startswith("cache:") and torch.equal(again, auto)
+    # ... and one in exact-fp32 mode does not: other key, fp32 kernels only
+    h2.set_precision(_hip.PREC_FP32)
+    exact = h2.forward(x, tb, 2, B)
+    assert {c[5].replace("+skip", "") for c in h2.conv_choices(2 * B, 16, 16)} == {"fp32"}
+    assert_close(exact.cpu().numpy(), auto.cpu().numpy(), rtol=1e-5, atol=1e-6, what="fp32 vs auto")
+    h.set_precision(_hip.PREC_AUTO)
