@@ -123,6 +123,7 @@ class PairWorkload:
         from distillation_trajectories_amd.utils.diffusion import (get_diffusion_params, psample_coefficients,
                                                                    timestep_indices)
         self.torch, self.engine, self.device, self.B, self.spec = torch, engine, device, batch, spec
+        self.collective = False
         H, T = spec["H"], spec["T"]
         self.H, self.T, self.E = H, T, C * H * H
         cfg = Config()
@@ -239,7 +240,7 @@ class PairWorkload:
         sums = eng.device_metric_sums(self.traj[0], self.traj[1])          # [B, T+1, 4] float64
         w1 = eng.device_wasserstein(self.traj[0], self.traj[1], self.w_index, self.w_rows)   # [B, T+1] float64
         local = torch.cat([sums.reshape(self.B, -1), w1], dim=1)
-        full = all_gather_rows(local, counts, dim=0) if world > 1 else local
+        full = all_gather_rows(local, counts, dim=0, force=True) if (world > 1 or self.collective) else local
         host = full.cpu().numpy()                                          # syncs the stream
         n = T + 1
         t_host0 = time.perf_counter() if t_gpu0 else 0.0
@@ -267,6 +268,7 @@ class GridWorkload:
         from distillation_trajectories_amd.models import DiffusionUNet
         from distillation_trajectories_amd.synthetic import make_model, noise_table
         self.torch, self.device, self.B, self.spec, self.rank = torch, device, batch, spec, rank
+        self.collective = False
         H, T = spec["H"], spec["T"]
         self.H, self.T = H, T
         self.cfg = Config()
@@ -293,7 +295,7 @@ class GridWorkload:
         from distillation_trajectories_amd import grid
         local = grid.hip_cell_metrics(self.teacher, self.students, self.cfg, self.spec["scales"], self.first, self.B,
                                       self.device, table=self.table, streams=None if self.concurrent else 1)
-        full = grid.all_gather_rows(local, counts, dim=2) if world > 1 else local
+        full = grid.all_gather_rows(local, counts, dim=2, force=True) if (world > 1 or self.collective) else local
         return full.cpu().numpy()
 
     def check(self, vals):
@@ -304,6 +306,29 @@ class GridWorkload:
 
 
 # ------------------------------------------------------------------------------------------- CPU legs (oracle)
+def usable_cores():
+    """(threads to use, host logical cores, cgroup CPU quota or None).  The GPU box shows all of the host's cores (256:
+    2 x EPYC 9575F) but grants this job a CPU quota (/sys/fs/cgroup/cpu.max, 16 per GPU): running more threads than the
+    quota only thrashes, so the CPU legs use min(affinity, quota) threads and the line states all three numbers."""
+    host = os.cpu_count() or 1
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // period)
+        except (OSError, ValueError):
+            pass
+    return (min(n, quota) if quota else n), host, quota
+
+
+
 def _oracle_models(spec):
     from distillation_trajectories_amd.config import Config
     from distillation_trajectories_amd.models import DiffusionUNet
@@ -326,7 +351,7 @@ def cpu_baseline(spec, batch=256, steps=8, pairs=8):
     from oracle import metrics_ref, sampler_ref
     H, T = spec["H"], spec["T"]
     prev_threads = torch.get_num_threads()
-    threads = min(16, os.cpu_count() or 1)          # the GPU box's CPU share per GPU
+    threads, host_cores, quota = usable_cores()     # every core this job may use, as the reference's CPU mode does (scripts/run_on_cpu.py:27)
     torch.set_num_threads(threads)
     params = sampler_ref.diffusion_params(T)
     g = torch.Generator().manual_seed(1234)
@@ -352,13 +377,13 @@ def cpu_baseline(spec, batch=256, steps=8, pairs=8):
     # per unit: sampler time + the pair's metric time spread over its 2*T trajectory-timesteps
     sec_per_unit = t_sample / units + t_metric_pair / (2 * T)
     torch.set_num_threads(prev_threads)
-    return {"value": round(1.0 / sec_per_unit, 2), "unit": "trajectory-timesteps/s", "cores": threads, "kind": "port",
+    return {"value": round(1.0 / sec_per_unit, 2), "unit": "trajectory-timesteps/s", "cores": threads, "host_cores": host_cores, "cpu_quota": quota, "kind": "port",
             "sample": f"oracle (torch-CPU restatement, {threads} threads): teacher+student p_sample loop, batch {batch}, "
                       f"{steps} of {T} timesteps, CFG 2 passes, + metrics on {pairs} pairs scaled to T+1 states; "
                       f"sampler {t_sample:.2f}s, metrics {t_metric_pair * 1e3:.1f} ms/pair"}
 
 
-def cpu_full_length(spec, host_inputs, gpu_vals, gpu_traj, max_seconds=40.0):
+def cpu_full_length(spec, host_inputs, gpu_vals, gpu_traj, max_seconds=40.0, fns=None):
     """Reference-faithful B=1 leg: the oracle's FULL-length loop (all T timesteps, 2 passes per step) for the first
     pairs of rank 0's batch on the very inputs the GPU used, plus the oracle's metric function on each pair.
     Returns (b1 timing object, metric_delta_vs_cpu object)."""
@@ -368,11 +393,11 @@ def cpu_full_length(spec, host_inputs, gpu_vals, gpu_traj, max_seconds=40.0):
     from oracle import metrics_ref, sampler_ref
     H, T = spec["H"], spec["T"]
     x_T, z, idx = host_inputs
-    threads = min(16, os.cpu_count() or 1)
+    threads, host_cores, quota = usable_cores()
     prev_threads = torch.get_num_threads()
     torch.set_num_threads(threads)
     params = sampler_ref.diffusion_params(T)
-    fns = _oracle_models(spec)
+    fns = fns or _oracle_models(spec)
     per_key, traj_err, done, t_loop, t_met = {}, 0.0, 0, 0.0, 0.0
     nan_mismatch = 0
     t_start = time.perf_counter()
@@ -412,7 +437,7 @@ def cpu_full_length(spec, host_inputs, gpu_vals, gpu_traj, max_seconds=40.0):
             done += 1
     torch.set_num_threads(prev_threads)
     units = 2 * done * T
-    b1 = {"value": round(units / (t_loop + t_met), 2), "unit": "trajectory-timesteps/s", "cores": threads, "kind": "port",
+    b1 = {"value": round(units / (t_loop + t_met), 2), "unit": "trajectory-timesteps/s", "cores": threads, "host_cores": host_cores, "cpu_quota": quota, "kind": "port",
           "sample": f"oracle, B=1 like the reference's loops: {done} pair(s), all {T} timesteps, 2 passes per step, + metric "
                     f"function per pair; sampler {t_loop:.2f}s, metrics {t_met * 1e3 / max(done, 1):.1f} ms/pair"}
     delta = {"pairs": done, "timesteps": T, "max_rel": max(per_key.values()) if per_key else None,
@@ -422,6 +447,54 @@ def cpu_full_length(spec, host_inputs, gpu_vals, gpu_traj, max_seconds=40.0):
              "note": "GPU metrics of rank 0's first pairs vs the oracle's full-length CPU loop on the same x_T / z / weights; "
                      "trajectory_mse compared as 1000 * mean step-MSE (pre-transform)"}
     return b1, delta
+
+
+def tame_pair_delta(spec, wl, device, scale=0.01):
+    """``metric_delta_vs_cpu`` in the INFORMATIVE regime.  The benchmark's random-init models diverge under the sampler
+    (endpoint distance in the hundreds), where four of the 19 scalar metrics sit at their floor or at NaN; here the same
+    two models with their final 1x1 layer scaled by ``scale`` (states stay O(1), teacher and student close) run the same
+    loop on rank 0's first pairs -- GPU sampler + metric kernels against the oracle's loop + metric function, all 19
+    metrics compared.  Outside the timed region."""
+    import copy
+    import torch
+    from distillation_trajectories_amd import engine
+    from distillation_trajectories_amd._hip import RULE_PSAMPLE
+    from oracle import unet_ref
+    x_T, z, idx = wl.host_inputs
+    B, T, H = x_T.shape[0], wl.T, wl.H
+    fns, trajs = [], []
+    for m in wl.models:
+        m2 = copy.deepcopy(m)
+        with torch.no_grad():
+            m2.final.weight.mul_(scale)
+            m2.final.bias.mul_(scale)
+        sd = {k: v.detach().cpu().clone() for k, v in m2.state_dict().items()}
+        fns.append(lambda x, t, c, sd=sd: unet_ref.unet_forward(sd, x, t, c))
+        h = engine.UNetHandle(m2.state_dict(), device)
+        tb = h.time_bias_general(wl.tb_t, wl.tb_cond, wl.tb_present, 2 * T)
+        traj = torch.empty(T + 1, B, wl.E, device=device)
+        traj[0].copy_(x_T.to(device))
+        zz = z.reshape(-1, wl.E).to(device)
+        shift, k = [], 0
+        for flag in wl.has_noise:
+            shift.append(k * B)
+            k += int(flag)
+        h.sample(RULE_PSAMPLE, traj, H, H, tb, 2, wl.coef, wl.has_noise, z=zz, z_shift=shift, w_scalar=spec["guidance"])
+        trajs.append(traj)
+    sums = engine.device_metric_sums(trajs[0], trajs[1])
+    w1 = engine.device_wasserstein(trajs[0], trajs[1], None, None) if wl.E <= 1000 else None
+    if w1 is None:
+        return None
+    host = torch.cat([sums.reshape(B, -1), w1], dim=1).cpu().numpy()
+    n = T + 1
+    vals = engine.batch_scalar_metrics(host[:, : 4 * n].reshape(-1, n, 4), host[:, 4 * n:], H * H, wl.E)
+    _, delta = cpu_full_length(spec, wl.host_inputs, vals, [t.cpu() for t in trajs], fns=fns)
+    delta["final_layer_scale"] = scale
+    delta["gpu_values_pair0"] = {k: float(f"{float(vals[k][0]):.6g}") for k in engine.SCALAR_KEYS}
+    delta["note"] = ("same models with final.weight / final.bias scaled by %g so that the states stay O(1) and teacher / student stay "
+                     "close: every one of the 19 scalar metrics is in its informative range (see gpu_values_pair0); GPU sampler + "
+                     "metric kernels vs the oracle's full-length CPU loop + metric function on the same x_T / z" % scale)
+    return delta
 
 
 def traffic_from_profiles(kernel_name):
@@ -463,7 +536,14 @@ def main():
         torch.cuda.set_device(dev_index)
         device = torch.device("cuda", dev_index)
     ranks = [{"rank": 0, "local_rank": 0, "device": dev_index, "pid": os.getpid()}]
-    if world > 1:
+    # DT_BENCH_NCCL1=1: a process group of ONE rank over nccl (= RCCL), so that the collective code path (barrier, the metric
+    # all-gather on device tensors, the max-over-ranks all-reduce) runs on a single-GPU box too
+    solo_group = world == 1 and not dry and os.environ.get("DT_BENCH_NCCL1") == "1"
+    if solo_group:
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or solo_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -489,6 +569,7 @@ def main():
     spec = CONFIGS[args.config]
     batch = args.batch or spec["batch"]
     wl = (GridWorkload if args.config == 2 else PairWorkload)(spec, device, rank, batch, concurrent=not args.serial)
+    wl.collective = solo_group
     counts = [batch] * world
 
     def barrier():
@@ -542,7 +623,9 @@ def main():
                  "native fp32 MFMA, chosen per layer)", "data": "synthetic",
         "config": wl.describe(world),
         "per_gpu": round(value / world, 1),
-        "ranks": ranks, "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
+        "ranks": ranks, "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if (world > 1 or solo_group) else None,
+        "collective_path": ("one-rank nccl group: barrier + metric all-gather on device tensors + all-reduce of the step time went through RCCL"
+                            if solo_group else None),
         "metric_check": wl.check(vals),
     }
     # launch plans in use (engine._Plans): "table:<sha1>" = the committed per-arch table, "heuristic", "tuned:<sha1>" only with DT_AUTOTUNE=1
@@ -603,6 +686,7 @@ def main():
             b1, delta = cpu_full_length(spec, wl.host_inputs, vals, gpu_traj)
             out["cpu_baseline"]["b1"] = b1
             out["metric_delta_vs_cpu"] = delta
+            out["metric_delta_vs_cpu_tame"] = tame_pair_delta(spec, wl, device)
         else:       # configs[4]: one full-length CPU pair would take minutes; a bounded batched sample only
             out["cpu_baseline"] = cpu_baseline(spec, batch=16, steps=2, pairs=1)
     if rank == 0:

@@ -88,7 +88,7 @@ def generate_samples(model, config, num_samples, device, fixed_samples=None):
         if fixed_samples is not None:
             x = fixed_samples[i:i + 1].clone().cpu().float()
             if x.shape[2] != image_size or x.shape[3] != image_size:
-                x = torch.nn.functional.interpolate(x, size=(image_size, image_size), mode="bilinear", align_corners=True)
+                x = engine.resize_bilinear(x, (image_size, image_size)).cpu()
         else:
             x = torch.randn(1, config.channels, image_size, image_size)
         starts.append(x)

@@ -47,33 +47,71 @@ def wasserstein_index_tables(seeds, n, E, sample_size=1000):
     return torch.from_numpy(tables), row
 
 
-def compute_trajectory_metrics(teacher_trajectory, student_trajectory, config=None):
-    """25-key metric dict for one (teacher, student) pair; same keys and types as the reference."""
+def _resize_like(Y, size, device):
+    """reference :40-52: every student entry resized to the teacher's H x W (bilinear, align_corners=True) -- one
+    dt_resize_bilinear launch over all entries."""
+    rows = [y.shape[0] for y in Y]
+    out = engine.resize_bilinear(torch.cat([y.detach().to(device=device, dtype=torch.float32) for y in Y]), size)
+    return list(torch.split(out, rows))
+
+
+def _prepare(teacher_trajectory, student_trajectory):
     X, Y = _images(teacher_trajectory), _images(student_trajectory)
     device = X[0].device if X[0].is_cuda else _metrics_device()
     if X[-1].shape != Y[-1].shape and X[-1].shape[2:] != Y[-1].shape[2:]:
-        # reference :40-52; never reached by the models of this repo (all preserve H, W)
-        Y = [torch.nn.functional.interpolate(y.to(device), size=X[0].shape[2:], mode="bilinear", align_corners=True)
-             for y in Y]
-    nT, nS = len(X), len(Y)
-    n = min(nT, nS)
-    shape = X[0].shape
-    pixels = shape[2] * shape[3]
-    elems = shape[1] * shape[2] * shape[3]          # reference's total_elements (:68) -- only documents E
-    Xd, Yd = _stack_on_device(X, device), _stack_on_device(Y, device)
-    E = Xd.shape[2]
-    sums = engine.device_metric_sums(Xd, Yd)[0].cpu().numpy()
-    # torch.mean divides by the FULL entry size (batch included)
-    resampled = None
-    if nT != nS:
-        longer, shorter = (Xd, Yd) if nT > nS else (Yd, Xd)
-        resampled = engine.device_resampled_distance(longer, shorter)[0].cpu().numpy()
-    # Wasserstein coordinates: one global-generator draw per zipped step, like the reference (:303)
-    cnt = min(1000, E)
-    draws = [np.random.choice(E, cnt, replace=False) for _ in range(n)]
-    index = None
-    if E > 1000:
-        index = torch.from_numpy(np.stack(draws).astype(np.int32)).unsqueeze(0).to(device)
-    w1 = engine.device_wasserstein(Xd, Yd, index)[0].cpu().numpy()
-    del elems
-    return engine.metrics_from_sums(sums, w1, nT, nS, pixels, E, resampled)
+        Y = _resize_like(Y, X[0].shape[2:], device)
+    return X, Y, device
+
+
+def compute_trajectory_metrics(teacher_trajectory, student_trajectory, config=None):
+    """25-key metric dict for one (teacher, student) pair; same keys and types as the reference."""
+    return compute_trajectory_metrics_many([(teacher_trajectory, student_trajectory)], config)[0]
+
+
+def compute_trajectory_metrics_many(pairs, config=None):
+    """``[compute_trajectory_metrics(t, s, config) for t, s in pairs]`` with the device work batched: pairs whose
+    trajectories have the same lengths and entry shape are stacked and reduced by ONE dt_traj_metrics, ONE
+    dt_traj_wasserstein (and one dt_traj_resampled_distance for unequal lengths) launch per group, followed by one
+    device-to-host copy; the scalar post-transforms then run per pair on the host.
+
+    The Wasserstein coordinates are drawn from the GLOBAL numpy generator pair by pair, one ``np.random.choice`` per zipped
+    step, exactly as a loop over the reference's function would (:303) -- also when E <= 1000, where the draw is a full
+    permutation that cannot change the result but does advance the generator."""
+    prepared, groups = [], {}
+    for k, (tt, st) in enumerate(pairs):
+        X, Y, device = _prepare(tt, st)
+        shape = tuple(X[0].shape)
+        E = int(np.prod(shape))
+        n = min(len(X), len(Y))
+        cnt = min(1000, E)
+        draws = [np.random.choice(E, cnt, replace=False) for _ in range(n)]
+        prepared.append((X, Y, device, shape, E, draws))
+        groups.setdefault((len(X), len(Y), shape, str(device)), []).append(k)
+    out = [None] * len(pairs)
+    for (nT, nS, shape, _), members in groups.items():
+        device, E = prepared[members[0]][2], prepared[members[0]][4]
+        P, n = len(members), min(nT, nS)
+        # [n, P, E]: every list entry [B,C,H,W] is ONE point of a trajectory (the reference's norms run over the whole entry)
+        Xd = torch.stack([_stack_on_device(prepared[k][0], device)[:, 0] for k in members], dim=1).contiguous()
+        Yd = torch.stack([_stack_on_device(prepared[k][1], device)[:, 0] for k in members], dim=1).contiguous()
+        parts = [engine.device_metric_sums(Xd, Yd).reshape(P, -1)]
+        if nT != nS:
+            longer, shorter = (Xd, Yd) if nT > nS else (Yd, Xd)
+            parts.append(engine.device_resampled_distance(longer, shorter))
+        index = index_row = None
+        if E > 1000:
+            index = torch.from_numpy(np.stack([np.stack(prepared[k][5]) for k in members]).astype(np.int32)).to(device)
+            index_row = torch.arange(P, dtype=torch.int32, device=device)
+        parts.append(engine.device_wasserstein(Xd, Yd, index, index_row))
+        host = torch.cat(parts, dim=1).cpu().numpy()                 # the one device-to-host copy of the group
+        n_max = max(nT, nS)
+        pixels = shape[2] * shape[3]
+        for row, k in enumerate(members):
+            sums = host[row, : 4 * n_max].reshape(n_max, 4)
+            off = 4 * n_max
+            resampled = None
+            if nT != nS:
+                resampled = host[row, off: off + n]
+                off += n
+            out[k] = engine.metrics_from_sums(sums, host[row, off: off + n], nT, nS, pixels, E, resampled)
+    return out

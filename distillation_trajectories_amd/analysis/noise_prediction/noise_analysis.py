@@ -26,8 +26,7 @@ def calculate_noise_metrics(teacher_noise, student_noise):
     """{'mse', 'mae', 'cosine_similarity'} as python floats (reference :43-85)."""
     if teacher_noise.shape != student_noise.shape:
         print(f"  Resizing student noise from {student_noise.shape} to {teacher_noise.shape}")
-        student_noise = torch.nn.functional.interpolate(student_noise, size=(teacher_noise.shape[2], teacher_noise.shape[3]),
-                                                        mode="bilinear", align_corners=True)
+        student_noise = engine.resize_bilinear(student_noise, (teacher_noise.shape[2], teacher_noise.shape[3]))
     if not teacher_noise.is_cuda:
         from ..metrics.trajectory_metrics import _metrics_device
         dev = _metrics_device()

@@ -41,6 +41,7 @@ struct ProfileScope {
 // scale = (in-1)/(out-1), 0 when out == 1; src = scale*dst), and the four-tap blend with its operation order fixed by
 // explicit fmaf so that every translation unit (whatever its fp-contract setting) produces the same bits
 __device__ inline void bilinear_src(int dst, int in, int out, int &i0, int &i1, float &l0, float &l1) {
+#pragma clang fp contract(off)   // src must be the ROUNDED product, as ATen forms it: fused into `src - i0` it moves the weights by up to 1 ulp of src (2e-6 at src = 31)
   const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
   const float src = scale * (float)dst;
   i0 = (int)src;

@@ -251,6 +251,53 @@ __global__ void head_upsample_kernel(const float *__restrict__ lowres, float *__
   }
 }
 
+// Bilinear resize of NCHW images with align_corners=True (torch.nn.functional.interpolate as the reference calls it for a
+// student that runs at another resolution: utils/trajectory_manager.py:153-163,298-305, analysis/metrics/trajectory_metrics.py:40-52).
+// One thread per four consecutive output pixels of a row (16-byte stores); HBM-bound.
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float *__restrict__ in, float *__restrict__ out, int planes,
+                                                              int h, int w, int H, int W) {
+  const int Wq = (W + 3) >> 2;
+  const size_t total = (size_t)planes * H * Wq;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int xq = i % Wq;
+    size_t r = i / Wq;
+    const int y = r % H;
+    const size_t pl = r / H;
+    int y0, y1;
+    float wy0, wy1;
+    bilinear_src(y, h, H, y0, y1, wy0, wy1);
+    const float *base = in + pl * (size_t)h * w;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x = xq * 4 + j;
+      v[j] = 0.f;
+      if (x < W) {
+        int x0, x1;
+        float wx0, wx1;
+        bilinear_src(x, w, W, x0, x1, wx0, wx1);
+        v[j] = bilinear_blend(base[(size_t)y0 * w + x0], base[(size_t)y0 * w + x1], base[(size_t)y1 * w + x0], base[(size_t)y1 * w + x1],
+                              wy0, wy1, wx0, wx1);
+      }
+    }
+    float *o = out + (pl * H + y) * (size_t)W + xq * 4;
+    if (W % 4 == 0) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+      for (int j = 0; j < 4 && xq * 4 + j < W; ++j) o[j] = v[j];
+  }
+}
+
+int launch_resize_bilinear(const float *in, float *out, int planes, int h, int w, int H, int W, hipStream_t s) {
+  if (!in || !out) return DT_E_NULL;
+  if (planes < 1 || h < 1 || w < 1 || H < 1 || W < 1) return DT_E_SHAPE;
+  const size_t total = (size_t)planes * H * ((W + 3) / 4);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  ProfileScope prof(KC_POOL, 0.0, 4.0 * planes * ((double)h * w + (double)H * W), s);
+  resize_bilinear_kernel<<<blocks, 256, 0, s>>>(in, out, planes, h, w, H, W);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 int launch_head(const float *lo, const float *wf, const float *bias, float *lowres, int Bt, int h, int w, int cp, int C, int c_real,
                 hipStream_t s) {
   if (C > 3) return DT_E_SHAPE;

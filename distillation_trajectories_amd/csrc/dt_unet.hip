@@ -31,6 +31,7 @@ int launch_resampled_distance(const float *L, const float *S, int n_long, int n_
                               hipStream_t s);
 int launch_pair_stats(const float *X, const float *Y, int n, int B, int E, double *out, hipStream_t s);
 int launch_sample_mean(const float *traj, int n, int B, int E, float *out, hipStream_t s);
+int launch_resize_bilinear(const float *in, float *out, int planes, int h, int w, int H, int W, hipStream_t s);
 }  // namespace dt
 
 using namespace dt;
@@ -991,6 +992,10 @@ int dt_pair_stats(const float *X, const float *Y, int n, int B, int E, double *o
 
 int dt_traj_sample_mean(const float *traj, int n, int B, int E, float *out, void *stream) {
   return launch_sample_mean(traj, n, B, E, out, (hipStream_t)stream);
+}
+
+int dt_resize_bilinear(const float *in, float *out, int planes, int h, int w, int H, int W, void *stream) {
+  return launch_resize_bilinear(in, out, planes, h, w, H, W, (hipStream_t)stream);
 }
 
 int dt_traj_resampled_distance(const float *L, const float *S, int n_long, int n_short, int B, int E, double *out,

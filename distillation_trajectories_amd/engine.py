@@ -105,6 +105,12 @@ class _Plans:
         return hashlib.sha1(json.dumps(plan, sort_keys=True).encode()).hexdigest()[:10]
 
 
+import weakref
+
+_HANDLES = weakref.WeakKeyDictionary()      # nn.Module -> (weights key, UNetHandle)
+_TRAIN_WARNED = weakref.WeakSet()
+
+
 class UNetHandle:
     """Owns one ``dt_unet`` (packed weights in HBM) built from a module's state_dict."""
 
@@ -158,17 +164,19 @@ class UNetHandle:
         would give different numbers in the reference, so that is reported once per module."""
         tensors = list(module.parameters()) + list(module.buffers())
         _require_cuda(tensors[0], "model parameters")
-        if module.training and not module.__dict__.get("_dt_hip_train_warned"):
+        # (the cache lives beside the module, not in its __dict__: a module that has run on the HIP path can still be
+        # deep-copied, pickled and torch.save()d like any other nn.Module)
+        if module.training and module not in _TRAIN_WARNED:
             import warnings
-            module.__dict__["_dt_hip_train_warned"] = True
+            _TRAIN_WARNED.add(module)
             warnings.warn("distillation_trajectories_amd: the model is in train mode, but the HIP path is inference-only "
                           "(BatchNorm running statistics, dropout off); call model.eval() as the reference's callers do",
                           RuntimeWarning, stacklevel=3)
         key = tuple((v.data_ptr(), v._version) for v in tensors)
-        cached = module.__dict__.get("_dt_hip_handle")
+        cached = _HANDLES.get(module)
         if cached is None or cached[0] != key:
             cached = (key, UNetHandle(module.state_dict(), tensors[0].device))
-            module.__dict__["_dt_hip_handle"] = cached
+            _HANDLES[module] = cached
         return cached[1]
 
     # ------------------------------------------------------------------ primitives
@@ -484,6 +492,23 @@ def device_sample_mean(traj):
     out = torch.empty(n, E, dtype=torch.float32, device=traj.device)
     with torch.cuda.device(traj.device):
         check(lib.dt_traj_sample_mean(ptr(traj), n, B, E, ptr(out), stream_ptr()), "dt_traj_sample_mean")
+    return out
+
+
+def resize_bilinear(images, size):
+    """``torch.nn.functional.interpolate(images, size=size, mode='bilinear', align_corners=True)`` for an NCHW fp32 tensor,
+    on the device (dt_resize_bilinear); a host tensor is uploaded and the result stays on the device."""
+    lib = _hip.load()
+    if not images.is_cuda:
+        if not torch.cuda.is_available():
+            raise HipLibraryError("resize_bilinear needs a HIP device; there is no CPU fallback")
+        images = images.to(torch.device("cuda", torch.cuda.current_device()))
+    x = images.detach().contiguous().float()
+    N, C, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.dt_resize_bilinear(ptr(x), ptr(out), N * C, h, w, H, W, stream_ptr()), "dt_resize_bilinear")
     return out
 
 

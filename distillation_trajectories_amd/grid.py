@@ -28,11 +28,13 @@ def shard_range(n, rank, world):
     return start, base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local, counts, dim):
+def all_gather_rows(local, counts, dim, force=False):
     """Concatenate every rank's ``local`` along ``dim`` (row counts may differ by one). No-op without a
-    process group.  Uses the default group's backend: nccl (= RCCL) on GPUs, gloo in the CPU tests."""
+    process group.  Uses the default group's backend: nccl (= RCCL) on GPUs, gloo in the CPU tests.
+    ``force``: run the collective also in a group of ONE rank (bench.py DT_BENCH_NCCL1=1: the RCCL code path on a
+    single-GPU box)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return local
     if dist.get_backend() != "nccl" and local.is_cuda:
         # CPU rehearsal backends (gloo): exchange on the host, hand the result back on the device

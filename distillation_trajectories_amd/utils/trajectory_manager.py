@@ -16,7 +16,7 @@ import torch
 
 from .. import engine
 from .._hip import COND_NONE, RULE_MANAGER
-from ..analysis.metrics.trajectory_metrics import compute_trajectory_metrics
+from ..analysis.metrics.trajectory_metrics import compute_trajectory_metrics, compute_trajectory_metrics_many
 
 
 def timestep_list(sample_steps, steps):
@@ -130,11 +130,13 @@ class TrajectoryManager:
         return getattr(self.student_model, "image_size", self.config.image_size)
 
     def _resize_student(self, student_trajectory, size):
-        if size == self.config.image_size:
+        """reference :153-163: every stored student state resized to the teacher's resolution (bilinear, align_corners=True);
+        one dt_resize_bilinear launch over the whole trajectory."""
+        if size == self.config.image_size or not student_trajectory:
             return student_trajectory
-        return [(torch.nn.functional.interpolate(img, size=(self.config.image_size, self.config.image_size),
-                                                 mode="bilinear", align_corners=True), t)
-                for img, t in student_trajectory]
+        imgs = torch.cat([img for img, _ in student_trajectory])
+        out = engine.resize_bilinear(imgs, (self.config.image_size, self.config.image_size))
+        return [(out[i:i + 1].clone(), t) for i, (_, t) in enumerate(student_trajectory)]
 
     def generate_trajectory(self, seed=None):
         """One (teacher, student) pair from seeded noise (reference :65-165)."""
@@ -157,7 +159,7 @@ class TrajectoryManager:
     def _update_x(self, x, noise_pred, t, noise):
         """Reference's placeholder update (:167-205) as one fused kernel launch."""
         if noise_pred.shape != x.shape:
-            noise_pred = torch.nn.functional.interpolate(noise_pred, size=x.shape[2:], mode="bilinear", align_corners=True)
+            noise_pred = engine.resize_bilinear(noise_pred, x.shape[2:])
         coef = self._manager_coefficients([t])[0]
         return engine.cfg_update(RULE_MANAGER, x.contiguous().float(), noise_pred.contiguous().float(), None,
                                  noise.contiguous().float(), coef, True)
@@ -181,7 +183,7 @@ class TrajectoryManager:
         size = self._student_size()
         start = sample.detach().cpu().float()
         if sample.shape[2] != size or sample.shape[3] != size:
-            start = torch.nn.functional.interpolate(start.clone(), size=(size, size), mode="bilinear", align_corners=True)
+            start = engine.resize_bilinear(start, (size, size)).cpu()
         print(f"Sample shape for student: {start.shape}")
         try:
             student_trajectory = self._run(self.student_model, start, timestep_list(cfg.sample_steps, cfg.student_steps))
@@ -263,10 +265,13 @@ class TrajectoryManager:
         same = ("path_length_similarity", "efficiency_similarity", "mean_velocity_similarity",
                 "mean_directional_consistency", "mean_position_difference", "distribution_similarity")
         for start in range(0, len(files), batch_size):
+            pairs = []
             for name in files[start:start + batch_size]:
                 with open(os.path.join(self.config.trajectory_dir, name), "rb") as f:
-                    t_traj, s_traj = pickle.load(f)
-                metrics = compute_trajectory_metrics(t_traj, s_traj, self.config)
+                    pairs.append(pickle.load(f))
+            # the pairs of a batch are reduced together: one launch of each metric kernel and one device-to-host copy per
+            # group of equal trajectory lengths instead of three launches and three syncs per pair
+            for metrics in compute_trajectory_metrics_many(pairs, self.config):
                 for dst, src in renamed:
                     all_metrics[dst].append(metrics[src])
                 for k in same:

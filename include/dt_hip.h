@@ -28,7 +28,8 @@ extern "C" {
 
 /* 2: time-bias rows carry enc1.conv2's class-bias columns (dt_unet_time_bias_stride), launch kind 5 and the 256 x 64 tile
  * in the conv-choice hooks; the exported symbols are those of version 1
- * 3: + dt_unet_forward_mixed / dt_sample_trajectory_mixed (single-pass and CFG images in one batch), dt_unet_declare_shape;
+ * 3: + dt_unet_forward_mixed / dt_sample_trajectory_mixed (single-pass and CFG images in one batch), dt_unet_declare_shape,
+ *    dt_resize_bilinear;
  *    dt_sample_trajectory accepts eps_scratch_dev == NULL */
 #define DT_ABI_VERSION 3
 
@@ -232,6 +233,11 @@ int dt_traj_wasserstein(const float *teacher_dev, const float *student_dev, int 
  * onto the shorter's normalised time grid, then |L'(t_i) - S_i|_2 in float64.  out_dist_dev[B][n_short] */
 int dt_traj_resampled_distance(const float *long_dev, const float *short_dev, int n_long, int n_short,
                                int B, int E, double *out_dist_dev, void *stream);
+
+/* Bilinear resize with align_corners=True of `planes` = N*C contiguous images [h][w] -> [H][W] (NCHW tensors, any ratio):
+ * torch.nn.functional.interpolate(img, size=(H, W), mode='bilinear', align_corners=True) as the reference applies it to a
+ * student that runs at another resolution (utils/trajectory_manager.py:153-163,298-305; trajectory_metrics.py:40-52). */
+int dt_resize_bilinear(const float *in_dev, float *out_dev, int planes, int h, int w, int H, int W, void *stream);
 
 /* Next-row reductions.
  * dt_pair_stats: evaluation/metrics.py:118-183 (compute_trajectory_divergence) and

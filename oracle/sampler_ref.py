@@ -158,16 +158,48 @@ def manager_trajectory(eps_fn, x0, indices, teacher_steps):
     return out
 
 
-def manager_generate(teacher_fn, student_fn, cfg, seed=None):
-    """utils/trajectory_manager.py:65-165 for equal image sizes."""
+def manager_generate(teacher_fn, student_fn, cfg, seed=None, student_image_size=None):
+    """utils/trajectory_manager.py:65-165.  ``student_image_size``: the student model's ``image_size`` attribute when it
+    has one (:120-122): its loop then runs at that resolution and every stored state is resized to the teacher's
+    (:153-163, bilinear, align_corners=True)."""
     shape = (1, cfg.channels, cfg.image_size, cfg.image_size)
     if seed is not None:
         torch.manual_seed(seed); np.random.seed(seed)
     tt = manager_trajectory(teacher_fn, torch.randn(*shape), manager_indices(cfg.sample_steps, cfg.teacher_steps), cfg.teacher_steps)
     if seed is not None:
         torch.manual_seed(seed); np.random.seed(seed)
-    st = manager_trajectory(student_fn, torch.randn(*shape), manager_indices(cfg.sample_steps, cfg.student_steps), cfg.teacher_steps)
+    size = cfg.image_size if student_image_size is None else student_image_size
+    st = manager_trajectory(student_fn, torch.randn(1, cfg.channels, size, size), manager_indices(cfg.sample_steps, cfg.student_steps),
+                            cfg.teacher_steps)
+    if size != cfg.image_size:
+        st = [(torch.nn.functional.interpolate(img, size=(cfg.image_size, cfg.image_size), mode="bilinear", align_corners=True), t)
+              for img, t in st]
     return tt, st
+
+
+def manager_metrics_batch(pairs, metric_fn):
+    """utils/trajectory_manager.py:434-548 compute_trajectory_metrics_batch on in-memory pairs: per-pair metric lists
+    (six renamed, six under their own names) and the ``_avg`` of every scalar list as ``sum(...) / len(...)``."""
+    renamed = (("wasserstein_distances", "mean_wasserstein"), ("wasserstein_distances_per_timestep", "wasserstein_distances"),
+               ("endpoint_distances", "endpoint_distance"), ("teacher_path_lengths", "teacher_path_length"),
+               ("student_path_lengths", "student_path_length"), ("teacher_efficiency", "teacher_efficiency"),
+               ("student_efficiency", "student_efficiency"))
+    same = ("path_length_similarity", "efficiency_similarity", "mean_velocity_similarity", "mean_directional_consistency",
+            "mean_position_difference", "distribution_similarity")
+    out = {k: [] for k, _ in renamed}
+    out.update({k: [] for k in same})
+    out["architecture_type"] = []
+    for tt, st in pairs:
+        m = metric_fn(tt, st)
+        for dst, src in renamed:
+            out[dst].append(m[src])
+        for k in same:
+            out[k].append(m[k])
+    for k in ("endpoint_distances", "teacher_path_lengths", "student_path_lengths", "teacher_efficiency", "student_efficiency",
+              "wasserstein_distances") + same:
+        if out[k]:
+            out[k + "_avg"] = sum(out[k]) / len(out[k])
+    return out
 
 
 # ----------------------------------------------------------------------------- grid driver

@@ -44,6 +44,16 @@ def golden_r02():
 
 
 @pytest.fixture(scope="session")
+def golden_r03():
+    """(arrays, meta) of tests/golden/make_golden_r03.py: compute_trajectory_metrics_batch aggregates, the student-resize
+    branches, one cell of the eight-scale grid of configs[3]."""
+    arrays = np.load(os.path.join(GOLDEN, "reference_vectors_r03.npz"))
+    with open(os.path.join(GOLDEN, "reference_vectors_r03.json")) as f:
+        meta = json.load(f)
+    return arrays, meta
+
+
+@pytest.fixture(scope="session")
 def models():
     """Seeded synthetic models (CPU weight containers), keyed by size factor; digests checked against golden."""
     from distillation_trajectories_amd.config import Config

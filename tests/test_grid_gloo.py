@@ -44,16 +44,32 @@ def oracle_cell_fn():
     return cell
 
 
+# configs[3] shape: 11 size factors x 8 guidance scales (scripts/analysis/analyze_trajectory_metrics.py:38-42), 13 samples
+# (ragged over two ranks: 7 + 6).  The cell values are a synthetic function of (student, scale, sample, metric) -- this leg
+# checks the shard / all-gather / sample-order-mean plumbing at the grid's real extent, the oracle-backed leg checks values.
+GS8 = [1.0, 2.0, 3.0, 5.0, 7.5, 10.0, 15.0, 20.0]
+N_SF, SAMPLES8 = 11, 13
+
+
+def synthetic_cell_fn(first, count):
+    i, j, s, k = np.meshgrid(np.arange(N_SF), np.arange(len(GS8)), first + np.arange(count), np.arange(K), indexing="ij")
+    v = np.sin(0.37 * i + 1.3 * j + 0.11 * k) * (1.0 + 0.01 * s) + 1e-3 * s * s
+    v[:, :, :, 2] = np.where((s[:, :, :, 2] + j[:, :, :, 2]) % 5 == 0, np.nan, v[:, :, :, 2])     # trajectory_mse goes NaN at high guidance
+    return torch.from_numpy(v)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        res8 = grid_metrics(None, [None] * N_SF, None, GS8, SAMPLES8, rank=rank, world=world, cell_fn=synthetic_cell_fn)
+        q.put((rank, "grid8", res8, None))
         res = grid_metrics(None, [None], None, GS, SAMPLES, rank=rank, world=world, cell_fn=oracle_cell_fn())
         # ragged all-gather on its own: rank r contributes r+2 rows
         rows = torch.full((rank + 2, 3), float(rank), dtype=torch.float64)
         cat = all_gather_rows(rows, [r + 2 for r in range(world)], dim=0)
-        q.put((rank, res, cat.tolist()))
+        q.put((rank, "cells", res, cat.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -72,11 +88,19 @@ def test_two_rank_grid_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get() for _ in procs]
+    single8 = grid_metrics(None, [None] * N_SF, None, GS8, SAMPLES8, rank=0, world=1, cell_fn=synthetic_cell_fn)
+    got = [q.get() for _ in range(2 * len(procs))]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    for rank, res, cat in got:
+    for rank, kind, res8, _ in (g for g in got if g[1] == "grid8"):
+        assert len(res8) == N_SF and all(set(cell) == set(GS8) for cell in res8)
+        for i in range(N_SF):
+            for gs in GS8:
+                for k in engine.SCALAR_KEYS:
+                    a, b = res8[i][gs][k], single8[i][gs][k]
+                    assert a == b or (np.isnan(a) and np.isnan(b)), (rank, i, gs, k, a, b)
+    for rank, kind, res, cat in (g for g in got if g[1] == "cells"):
         assert cat == [[0.0] * 3] * 2 + [[1.0] * 3] * 3
         for gs in GS:
             for k in engine.SCALAR_KEYS:

@@ -981,3 +981,108 @@ def test_plan_cache_respects_arithmetic_mode(gpu_models, tmp_path, monkeypatch):
     assert {c[5].replace("+skip", "") for c in h2.conv_choices(2 * B, 16, 16)} == {"fp32"}
     assert_close(exact.cpu().numpy(), auto.cpu().numpy(), rtol=1e-5, atol=1e-6, what="fp32 vs auto")
     h.set_precision(_hip.PREC_AUTO)
+
+
+# ------------------------------------------------------------------ round 3: batch aggregates, resize, eight scales
+def _check_aggregate(got, want, rel):
+    assert set(got) == set(want), set(got) ^ set(want)
+    for k, w in want.items():
+        g = got[k]
+        if isinstance(w, list):
+            assert len(g) == len(w), k
+            if w:
+                assert_close(np.array(g, dtype=np.float64), np.array(w, dtype=np.float64), rtol=rel, atol=1e-7, what=k)
+        else:
+            assert_close(float(g), float(w), rtol=rel, atol=1e-9, what=k)
+
+
+def test_r03_metrics_batch_aggregates_golden(golden_r03, gpu_models, tmp_path):
+    """TrajectoryManager.compute_trajectory_metrics_batch (utils/trajectory_manager.py:434-548) against the reference's own
+    aggregate over three generated-and-stored pairs: every list, every ``_avg`` key, wasserstein_distances_per_timestep --
+    equal lengths (21 / 21 states) and the interp1d path (21 / 6).  The pairs of a batch are reduced by one launch of each
+    metric kernel (compute_trajectory_metrics_many)."""
+    from distillation_trajectories_amd.utils.trajectory_manager import TrajectoryManager
+    _, meta = golden_r03
+    for n, c in enumerate(meta["batch_metric_cases"]):
+        cfg = Config()
+        cfg.image_size, cfg.sample_steps = 16, c["sample_steps"]
+        cfg.teacher_steps, cfg.student_steps = c["teacher_steps"], c["student_steps"]
+        cfg.trajectory_dir = str(tmp_path / f"traj{n}")
+        man = TrajectoryManager(gpu_models(c["teacher_sf"]), gpu_models(c["student_sf"]), cfg, size_factor=c["student_sf"])
+        assert len(man.generate_and_save_trajectories(num_samples=c["num_samples"])) == c["num_samples"]
+        np.random.seed(c["np_seed"])
+        got = man.compute_trajectory_metrics_batch()
+        _check_aggregate(got, c["result"], rel=1e-4)
+        # batch_size = 1 walks the same pairs one launch group at a time: identical numbers
+        np.random.seed(c["np_seed"])
+        one = man.compute_trajectory_metrics_batch(batch_size=1)
+        assert all(np.array_equal(np.asarray(one[k], dtype=np.float64), np.asarray(got[k], dtype=np.float64)) for k in got if k != "architecture_type")
+
+
+def test_r03_student_resize_branches_golden(golden_r03, gpu_models, tmp_path):
+    """The student at another resolution: dt_resize_bilinear in the manager (utils/trajectory_manager.py:120-122,153-163) and
+    in compute_trajectory_metrics (analysis/metrics/trajectory_metrics.py:40-52), against the reference's outputs."""
+    import copy
+    from distillation_trajectories_amd.analysis.metrics.trajectory_metrics import compute_trajectory_metrics
+    from distillation_trajectories_amd.utils.trajectory_manager import TrajectoryManager
+    arrays, meta = golden_r03
+    c = meta["resize_case"]
+    cfg = Config()
+    cfg.image_size, cfg.sample_steps = 16, c["sample_steps"]
+    cfg.teacher_steps, cfg.student_steps = c["teacher_steps"], c["student_steps"]
+    cfg.trajectory_dir = str(tmp_path / "traj")
+    student = copy.deepcopy(gpu_models(c["student_sf"]))
+    student.image_size = c["student_image_size"]
+    man = TrajectoryManager(gpu_models(c["teacher_sf"]), student, cfg, size_factor=c["student_sf"])
+    tt, st = man.generate_trajectory(seed=c["seed"])
+    assert [t for _, t in tt] == c["teacher_t"] and [t for _, t in st] == c["student_t"]
+    assert st[0][0].shape == (1, 3, 16, 16)
+    assert_close(torch.stack([x.cpu() for x, _ in tt]).numpy(), arrays["resize_teacher"], rtol=1e-4, atol=1e-4)
+    assert_close(torch.stack([x.cpu() for x, _ in st]).numpy(), arrays["resize_student"], rtol=1e-4, atol=1e-4)
+    # the first stored student state is the resized start noise: isolates the resize kernel (no model in between)
+    assert_close(st[0][0].cpu().numpy(), arrays["resize_student"][0], rtol=1e-6, atol=1e-6, what="resized x_T")
+    a = [torch.from_numpy(x) for x in arrays["resize_metric_teacher"]]
+    b = [torch.from_numpy(x) for x in arrays["resize_metric_student32"]]
+    np.random.seed(c["metric_np_seed"])
+    _check_metrics(compute_trajectory_metrics(a, b, cfg), c["metrics"], rel=2e-5)
+
+
+@pytest.mark.parametrize("shape", [((2, 3, 32, 32), (16, 16)), ((1, 3, 16, 16), (32, 32)), ((3, 1, 10, 7), (13, 22)), ((1, 2, 5, 5), (5, 5)),
+                                   ((2, 3, 8, 8), (1, 1))])
+def test_resize_bilinear_matches_torch(shape):
+    """dt_resize_bilinear against torch.nn.functional.interpolate(mode='bilinear', align_corners=True) on the CPU: down, up,
+    odd non-square sizes, identity and a single output pixel."""
+    (N, C, h, w), size = shape
+    x = torch.randn(N, C, h, w, generator=torch.Generator().manual_seed(h * 100 + w))
+    want = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=True)
+    got = engine.resize_bilinear(x.to(DEV), size)
+    assert got.shape == want.shape
+    assert_close(got.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6, what=str(shape))
+
+
+def test_r03_eight_scale_grid_cell_golden(golden_r03, gpu_models):
+    """configs[3]: the eight guidance scales {1, 2, 3, 5, 7.5, 10, 15, 20} (scripts/analysis/analyze_trajectory_metrics.py:40-42)
+    in ONE mixed launch sequence per model (1 single-pass + 7 CFG row blocks: 15 x S rows per forward), through
+    compare_trajectories and through the grid driver, against the reference's cell."""
+    from distillation_trajectories_amd.analysis.trajectory_engine import compare_trajectories
+    from distillation_trajectories_amd.grid import grid_metrics
+    _, meta = golden_r03
+    c = meta["grid8_cell"]
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = 16, c["T"]
+    teacher, student = gpu_models(c["teacher_sf"]), gpu_models(c["student_sf"])
+    res = compare_trajectories(teacher, student, cfg, guidance_scales=c["guidance_scales"], size_factor=c["student_sf"],
+                               num_samples=c["num_samples"])
+    for side in ("teacher_metrics", "student_metrics"):
+        for gs in c["guidance_scales"]:
+            _check_metrics(res[side][gs], c["result"][side][str(gs)], rel=1e-4)
+    grid = grid_metrics(teacher, [student], cfg, c["guidance_scales"], num_samples=c["num_samples"], rank=0, world=1)
+    for gs in c["guidance_scales"]:
+        want = c["result"]["teacher_metrics"][str(gs)]
+        assert set(want) <= set(grid[0][gs])      # (the reference's average skips np.float32-valued keys such as path_alignment)
+        for k, w in want.items():
+            v = grid[0][gs][k]
+            if math.isnan(w):
+                assert math.isnan(v), (gs, k)
+            else:
+                assert_close(v, w, rtol=1e-4, atol=1e-9, what=f"grid gs={gs} {k}")

@@ -268,3 +268,65 @@ def test_r02_config4_tail_from_stored_state(golden_r02, models):
             assert np.array_equal(x.numpy(), tail[k - c["first_entry"] + 1]), k
             if k - c["first_entry"] >= 5:      # the oracle is the same torch code path: six steps pin it, the GPU test runs all
                 break
+
+
+# ------------------------------------------------------------------ round 3: batch aggregates, resize branches, 8 scales
+def _check_value(got, want, what):
+    if isinstance(want, list):
+        assert len(got) == len(want), what
+        for i, (g, w) in enumerate(zip(got, want)):
+            _check_value(g, w, f"{what}[{i}]")
+    else:
+        assert _close(got, want), (what, got, want)
+
+
+def test_r03_metrics_batch_aggregates(golden_r03, models):
+    """utils/trajectory_manager.py:434-548 on three stored pairs (equal lengths, and 21 vs 6 states: interp1d path)."""
+    _, meta = golden_r03
+    for c in meta["batch_metric_cases"]:
+        cfg = Config()
+        cfg.image_size, cfg.sample_steps = 16, c["sample_steps"]
+        cfg.teacher_steps, cfg.student_steps = c["teacher_steps"], c["student_steps"]
+        with torch.no_grad():
+            pairs = [sampler_ref.manager_generate(eps_fn(models(c["teacher_sf"])), eps_fn(models(c["student_sf"])), cfg, seed=i)
+                     for i in range(c["num_samples"])]
+        np.random.seed(c["np_seed"])
+        got = sampler_ref.manager_metrics_batch(pairs, metrics_ref.compute_trajectory_metrics)
+        want = c["result"]
+        assert set(got) == set(want), set(got) ^ set(want)
+        for k, w in want.items():
+            _check_value(got[k], w, f"{c['student_steps']} student steps: {k}")
+
+
+def test_r03_student_resize_branches(golden_r03, models):
+    """A student with image_size 32 under config.image_size 16 (utils/trajectory_manager.py:120-122,153-163) and the metric
+    function's own resize of an unresized 32 x 32 student list (analysis/metrics/trajectory_metrics.py:40-52)."""
+    arrays, meta = golden_r03
+    c = meta["resize_case"]
+    cfg = Config()
+    cfg.image_size, cfg.sample_steps = 16, c["sample_steps"]
+    cfg.teacher_steps, cfg.student_steps = c["teacher_steps"], c["student_steps"]
+    with torch.no_grad():
+        tt, st = sampler_ref.manager_generate(eps_fn(models(c["teacher_sf"])), eps_fn(models(c["student_sf"])), cfg, seed=c["seed"],
+                                              student_image_size=c["student_image_size"])
+    assert [t for _, t in tt] == c["teacher_t"] and [t for _, t in st] == c["student_t"]
+    assert np.array_equal(torch.stack([x for x, _ in tt]).numpy(), arrays["resize_teacher"])
+    assert np.array_equal(torch.stack([x for x, _ in st]).numpy(), arrays["resize_student"])
+    a = [torch.from_numpy(x) for x in arrays["resize_metric_teacher"]]
+    b = [torch.from_numpy(x) for x in arrays["resize_metric_student32"]]
+    np.random.seed(c["metric_np_seed"])
+    _check_metrics(metrics_ref.compute_trajectory_metrics(a, b), c["metrics"])
+
+
+def test_r03_eight_scale_grid_cell(golden_r03, models):
+    """configs[3]: the eight guidance scales of scripts/analysis/analyze_trajectory_metrics.py:40-42 in one compare_trajectories call."""
+    _, meta = golden_r03
+    c = meta["grid8_cell"]
+    cfg = Config()
+    cfg.image_size, cfg.timesteps = 16, c["T"]
+    with torch.no_grad():
+        res = sampler_ref.compare_trajectories(eps_fn(models(c["teacher_sf"])), eps_fn(models(c["student_sf"])), cfg,
+                                               guidance_scales=c["guidance_scales"], num_samples=c["num_samples"])
+    for side in ("teacher_metrics", "student_metrics"):
+        for gs in c["guidance_scales"]:
+            _check_metrics(res[side][gs], c["result"][side][str(gs)])
