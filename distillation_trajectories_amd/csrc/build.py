@@ -94,5 +94,34 @@ def build(force=False, verbose=False, tools=False):
     return LIB
 
 
+SAN_DRIVER = os.path.join(OBJ_DIR, "dt_host_sanitize")
+
+
+def build_sanitizer_driver(verbose=False):
+    """tests/host_sanitize/driver.cpp + every library source, HOST code instrumented with AddressSanitizer and
+    UndefinedBehaviorSanitizer (``-Xarch_host -fsanitize=...``; device code is left alone: GPU ASan is unavailable on this
+    pool), one executable csrc/_build/dt_host_sanitize.  Cross-compiles without a GPU; tests/test_host_sanitize.py runs it
+    on the GPU box."""
+    hipcc = hipcc_path()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    root = os.path.dirname(os.path.dirname(HERE))
+    driver = os.path.join(root, "tests", "host_sanitize", "driver.cpp")
+    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [driver, os.path.abspath(__file__)]
+    if not _newer(SAN_DRIVER, deps):
+        return SAN_DRIVER
+    san = ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fsanitize=undefined", "-Xarch_host", "-fno-omit-frame-pointer"]
+    cmd = ([hipcc, f"--offload-arch={ARCH}", "-O1", "-g", "-std=c++17", "-Wno-unused-function", "-x", "hip"] + san +
+           [os.path.join(HERE, f) for f in SOURCES] + [driver, "-o", SAN_DRIVER])
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError(f"sanitizer driver build failed with exit code {res.returncode}")
+    return SAN_DRIVER
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, tools="--tools" in sys.argv))
+    if "--sanitize" in sys.argv:
+        print(build_sanitizer_driver(verbose=True))

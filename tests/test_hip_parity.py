@@ -1086,3 +1086,36 @@ def test_r03_eight_scale_grid_cell_golden(golden_r03, gpu_models):
                 assert math.isnan(v), (gs, k)
             else:
                 assert_close(v, w, rtol=1e-4, atol=1e-9, what=f"grid gs={gs} {k}")
+
+
+def test_non_finite_input_stays_in_its_own_image(gpu_models):
+    """An Inf pixel: the reference's fp32 convolution carries Inf / NaN through that image; here the three-way bf16 split turns
+    Inf into NaN one layer earlier (Inf - Inf) -- either way the image's prediction is non-finite, which is what is pinned,
+    together with the property that matters for a batched sampler: the OTHER images of the batch are bit-identical to a
+    clean run (rows are independent; zero-padded channels of the poisoned rows never leak)."""
+    m = gpu_models(0.5)
+    h = engine.UNetHandle.for_module(m)
+    B = 5
+    x = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(8)).to(DEV)
+    tb = h.time_bias([30, 30], [_hip.COND_NONE, _hip.COND_ONE])
+    clean = h.forward(x, tb, 2, B, tune=False).clone()
+    bad = x.clone()
+    bad[2, 1, 7, 9] = float("inf")
+    got = h.forward(bad, tb, 2, B, tune=False)
+    keep = [0, 1, 3, 4]
+    for p in (0, 1):
+        assert torch.equal(got[p * B:(p + 1) * B][keep], clean[p * B:(p + 1) * B][keep])
+        assert not torch.isfinite(got[p * B + 2]).all()
+    assert torch.isfinite(clean).all()
+
+
+def test_four_channel_images_are_rejected_cleanly():
+    """The library supports 1-3 image channels (the reference's datasets: MNIST 1, CIFAR-10 3); a 4-channel model fails at
+    dt_unet_create with DT_E_SHAPE -- raised, not a silent fallback."""
+    from distillation_trajectories_amd.models import DiffusionUNet
+    from distillation_trajectories_amd.synthetic import make_model
+    cfg = Config()
+    cfg.image_size, cfg.channels = 16, 4
+    m = make_model(DiffusionUNet, cfg, 0.2).to(DEV)
+    with pytest.raises(_hip.HipLibraryError, match="unsupported or inconsistent shape"):
+        m(torch.zeros(1, 4, 16, 16, device=DEV), torch.tensor([3], device=DEV))
