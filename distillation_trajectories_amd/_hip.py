@@ -12,7 +12,7 @@ COND_NONE, COND_ZERO, COND_ONE = 0, 1, 2
 RULE_ENGINE, RULE_PSAMPLE, RULE_MANAGER = 0, 1, 2
 PREC_FP32, PREC_SPLIT_BF16, PREC_AUTO = 0, 1, 2
 BT_COUNT, GT_COUNT, N_BLOCKS = 16, 9, 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):
@@ -41,6 +41,8 @@ SIGNATURES = {
     "dt_unet_declare_shape": (c_int, [c_void_p] + [c_int] * 5),
     "dt_unet_set_precision": (c_int, [c_void_p, c_int]),
     "dt_unet_set_head_fusion": (c_int, [c_void_p, c_int]),
+    "dt_unet_set_fused": (c_int, [c_void_p, c_int]),
+    "dt_unet_fused_active": (c_int, [c_void_p, c_int, c_int]),
     "dt_unet_time_conv": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, c_size_t, c_void_p, POINTER(c_float), POINTER(c_double)]),
     "dt_unet_debug_activation": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_size_t), POINTER(c_int),

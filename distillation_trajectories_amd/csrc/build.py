@@ -11,8 +11,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["dt_conv.hip", "dt_conv_bf16.hip", "dt_conv_strip.hip", "dt_layers.hip", "dt_update.hip", "dt_metrics.hip", "dt_unet.hip"]
-HEADERS = ["dt_internal.h", "dt_conv_epilogue.h", os.path.join("..", "..", "include", "dt_hip.h")]
+SOURCES = ["dt_conv.hip", "dt_conv_bf16.hip", "dt_conv_strip.hip", "dt_layers.hip", "dt_update.hip", "dt_metrics.hip", "dt_fused.hip", "dt_unet.hip"]
+HEADERS = ["dt_internal.h", "dt_conv_epilogue.h", "dt_update_math.h", "dt_fused.h", os.path.join("..", "..", "include", "dt_hip.h")]
 LIB = os.path.join(HERE, "libdt_hip.so")
 ARCH = "gfx950"
 

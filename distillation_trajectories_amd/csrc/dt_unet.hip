@@ -15,6 +15,7 @@
 #include <new>
 #include <vector>
 
+#include "dt_fused.h"
 #include "dt_internal.h"
 
 namespace dt {
@@ -61,7 +62,8 @@ const char *kClassName[KC_COUNT] = {
     "conv_strip_bf16x6_kernel<128,128>", "conv_strip_bf16x6_kernel<128,64>", "conv_strip_bf16x6_kernel<64,128>",
     "conv_strip_bf16x6_kernel<64,64>", "conv_strip_bf16x6_kernel<256,64>", "conv_strip_bf16x6_kernel<128,64,K2>",
     "conv_strip_bf16x6_kernel<64,64,K4>", "conv_strip_bf16x6_kernel<64,128,K2>", "splitk_epilogue_kernel", "first_conv_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
-    "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel"};
+    "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel",
+    "unet_fused_kernel"};
 }  // namespace
 
 namespace dt {
@@ -141,6 +143,16 @@ struct dt_unet {
   size_t slab_floats;
   TembWeights tw;
   const float *final_w, *final_b;   // borrowed? no: copied into the slab
+  // Small models (padded dims <= 32 / 64) at 16 x 16: the whole forward -- and the whole sampler loop -- is ONE launch of
+  // unet_fused_kernel (dt_fused.hip) with every activation in LDS.  fused_ok: the packs below exist; fused_on: the switch
+  // (dt_unet_set_fused; DT_NO_FUSED=1 at create time starts with it off).
+  bool fused_ok = false, fused_on = false;
+  int fused_G = 2;
+  float *fused_slab = nullptr;      // packed fp32 weights of the fused kernel + its layer table
+  FusedOp *fused_ops_dev = nullptr;
+  int fused_n_ops = 0;
+  FusedLds fused_lds{};
+  int fused_par = 0, fused_n_par = 0;   // the parameter block inside the fused slab
 };
 
 namespace {
@@ -149,6 +161,9 @@ struct Bump {
   size_t off = 0;
   size_t take(size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; }   // 256-B aligned
 };
+
+bool use_fused(const dt_unet *u, int H, int W);
+void fused_common(const dt_unet *u, FusedArgs &a, int B, int n_pass, int B_single, const float *tb, int tb_div);
 
 // activation buffers of one forward, as float offsets into the workspace
 struct Plan {
@@ -361,6 +376,13 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
   note_shape(u, Bt, H, W, B, B_single);
   const Plan pl = make_plan(u, Bt, H, W);
   if (pl.total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
+  if (use_fused(u, H, W) && eps) {           // small model: the whole forward is one launch (dt_fused.hip)
+    if (Bt % tb_div) return DT_E_ARG;
+    FusedArgs a{};
+    fused_common(u, a, B, n_pass, B_single, tb, tb_div);
+    a.mode = FUSED_FORWARD; a.x = x; a.eps = eps;
+    return launch_unet_fused(a, s);
+  }
   const TunedShape *tuned = find_tuned(u, Bt, H, W, B, B_single);
   int st = DT_OK;
   const float *cur = x;                     // enc1 reads the NCHW image itself (first-layer kernel, skip in conv2's epilogue)
@@ -399,6 +421,90 @@ int forward_impl(const dt_unet *u, const float *x, int B, int n_pass, int H, int
 // float offset of the low-resolution head output [Bt][H/2][W/2][4] inside the workspace
 size_t lowres_offset(const dt_unet *u, int Bt, int H, int W) { return make_plan(u, Bt, H, W).lowres; }
 
+
+// ---- the fused small-model path (dt_fused.hip): packs + layer table at create time, one launch per forward / sampler call
+int build_fused(dt_unet *u, const float *const *bt, hipStream_t s) {
+  const int C = u->desc.channels, c0p = u->cp[0], c1p = u->cp[1];
+  if (u->cp[2] != c1p || u->cp[3] != c1p || u->desc.dims[2] != u->desc.dims[1] || u->desc.dims[3] != u->desc.dims[1]) return DT_OK;
+  if (!fused_eligible(C, c0p, c1p)) return DT_OK;
+  const int G = u->fused_G;
+  if (fused_lds_bytes(G, c0p, c1p) > 160 * 1024) return DT_OK;
+  // one slab: the parameter block (per block the folded BN vectors of conv1 / conv2 and the skip conv's bias, cout_p floats each,
+  // then enc1's image-skip rows: the kernel copies this block into LDS), the packed weights of conv1 (blocks 1..7), conv2
+  // (all) and the 1x1 skip convs (enc1's image skip aside), enc1.conv1 as two K chunks, and the layer table
+  Bump bump;
+  const int tb_cols = 2 * c0p + 6 * c1p;
+  const size_t o_par = bump.take((size_t)5 * tb_cols + 4 * c0p);
+  size_t o1[kBlocks] = {}, o2[kBlocks] = {}, orr[kBlocks] = {};
+  for (int j = 0; j < kBlocks; ++j) {
+    const BlockW &k = u->blk[j];
+    if (j > 0) o1[j] = bump.take((size_t)9 * k.cin_p * k.cout_p);
+    o2[j] = bump.take((size_t)9 * k.cout_p * k.cout_p);
+    if (k.has_res && j > 0) orr[j] = bump.take((size_t)k.cin_p * k.cout_p);
+  }
+  const size_t o_wf = bump.take((size_t)2 * (c0p / 16) * 256);
+  const size_t o_ops = bump.take((sizeof(FusedOp) * kFusedMaxOps + 3) / 4);
+  if (bump.off >= (1u << 30)) return DT_OK;                     // offsets are ints
+  hipError_t e = hipMalloc((void **)&u->fused_slab, bump.off * sizeof(float));
+  if (e != hipSuccess) return (int)e;
+  float *F = u->fused_slab;
+  FusedModel m{};
+  m.c0p = c0p; m.c1p = c1p; m.wf = (int)o_wf; m.w3 = 5 * tb_cols;
+  int st = DT_OK;
+  auto d2d = [&](size_t off, const float *src, size_t n) {
+    if (st == DT_OK) {
+      const hipError_t ee = hipMemcpyAsync(F + off, src, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+      if (ee != hipSuccess) st = (int)ee;
+    }
+  };
+  st = launch_pack_fused_first(bt[DT_BT_CONV1_W], F + o_wf, u->blk[0].cout, C, c0p / 16, s);
+  d2d(o_par + 5 * tb_cols, u->blk[0].w3, (size_t)4 * c0p);
+  int pj = 0;                                                   // the block's offset inside the parameter block
+  for (int j = 0; j < kBlocks && st == DT_OK; ++j) {
+    const BlockW &k = u->blk[j];
+    const float *const *t = bt + j * DT_BT_COUNT;
+    FusedBlockW &f = m.blk[j];
+    const int cp = k.cout_p;
+    d2d(o_par + pj, k.s1, cp); d2d(o_par + pj + cp, k.h1, cp); d2d(o_par + pj + 2 * cp, k.s2, cp); d2d(o_par + pj + 3 * cp, k.h2, cp);
+    if (k.has_res && j > 0) d2d(o_par + pj + 4 * cp, k.hr, cp);
+    f.tb_off = k.tb_off;
+    f.c1 = FusedConvW{(int)o1[j], pj, pj + cp};
+    f.c2 = FusedConvW{(int)o2[j], pj + 2 * cp, pj + 3 * cp};
+    f.cr = FusedConvW{(int)orr[j], 0, pj + 4 * cp};
+    pj += 5 * cp;
+    if (j > 0) st = launch_pack_fused_conv(t[DT_BT_CONV1_W], F + o1[j], k.cout, k.cin, 9, k.cin_p / 16, k.cout_p / 16, k.split_c, k.split_cp, s);
+    if (!st) st = launch_pack_fused_conv(t[DT_BT_CONV2_W], F + o2[j], k.cout, k.cout, 9, k.cout_p / 16, k.cout_p / 16, k.cout, k.cout_p, s);
+    if (!st && k.has_res && j > 0)
+      st = launch_pack_fused_conv(t[DT_BT_RES_W], F + orr[j], k.cout, k.cin, 1, k.cin_p / 16, k.cout_p / 16, k.split_c, k.split_cp, s);
+  }
+  if (st == DT_OK && hipMemsetAsync(F + o_par + 4 * c0p, 0, sizeof(float) * c0p, s) != hipSuccess) st = (int)hipGetLastError();   // (enc1 has no skip-conv bias)
+  u->fused_par = (int)o_par; u->fused_n_par = 5 * tb_cols + 4 * c0p;
+  if (st != DT_OK) return st;
+  FusedOp ops[kFusedMaxOps];
+  u->fused_n_ops = fused_ops(m, G, ops);
+  u->fused_ops_dev = reinterpret_cast<FusedOp *>(F + o_ops);
+  // (a synchronous copy: `ops` lives on this stack frame)
+  e = hipMemcpy(u->fused_ops_dev, ops, sizeof(FusedOp) * u->fused_n_ops, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return (int)e;
+  u->fused_lds = fused_lds(G, c0p, c1p);
+  u->fused_ok = true;
+  u->fused_on = getenv("DT_NO_FUSED") == nullptr;
+  return DT_OK;
+}
+
+// (head fusion off = the test hook that materialises every block output in the workspace: only the layered path has those)
+bool use_fused(const dt_unet *u, int H, int W) { return u->fused_ok && u->fused_on && u->head_fusion && H == 16 && W == 16; }
+
+void fused_common(const dt_unet *u, FusedArgs &a, int B, int n_pass, int B_single, const float *tb, int tb_div) {
+  a.ops = u->fused_ops_dev; a.n_ops = u->fused_n_ops; a.fbase = u->fused_slab; a.par = u->fused_par; a.n_par = u->fused_n_par;
+  a.head_w = u->final_w; a.head_b = u->final_b;
+  a.tb = tb; a.tb_stride = u->tb_stride; a.tb_div = tb_div;
+  a.lds = u->fused_lds; a.G = u->fused_G;
+  a.C = u->desc.channels; a.c0 = u->desc.dims[0]; a.c0p = u->cp[0];
+  a.B = B; a.n_pass = n_pass; a.B_single = B_single;
+  a.tb_rows = (B * n_pass - B_single * (n_pass - 1)) / tb_div;
+  a.flops_per_row = fused_flops_per_row(a.C, u->desc.dims[0], u->desc.dims[1]);
+}
 }  // namespace
 
 extern "C" {
@@ -529,6 +635,8 @@ int dt_unet_create(const dt_unet_desc *desc, const float *const *bt, const float
   u->tw = TembWeights{S + o_fr, S + o_w1g, S + o_b1g, S + o_wc0, S + o_bc0, S + o_wc2, S + o_bc2, S + o_wt, S + o_bt,
                       D, half, u->tb_stride, tb, u->share_enc1 ? S + o_w2t : nullptr, c0p};
   u->final_w = S + o_fw; u->final_b = S + o_fb;
+  st = build_fused(u, bt, s);
+  if (st != DT_OK) { (void)hipFree(u->slab); if (u->fused_slab) (void)hipFree(u->fused_slab); delete u; return st; }
   *out = u;
   return DT_OK;
 }
@@ -537,6 +645,7 @@ void dt_unet_destroy(dt_unet *h) {
   if (!h) return;
   drop_graphs(h);
   if (h->slab) (void)hipFree(h->slab);
+  if (h->fused_slab) (void)hipFree(h->fused_slab);
   delete h;
 }
 
@@ -753,6 +862,18 @@ int dt_unet_set_head_fusion(dt_unet *h, int on) {
   return DT_OK;
 }
 
+int dt_unet_set_fused(dt_unet *h, int on) {
+  if (!h) return DT_E_NULL;
+  h->fused_on = on != 0 && h->fused_ok;
+  drop_graphs(h);
+  return DT_OK;
+}
+
+int dt_unet_fused_active(const dt_unet *h, int H, int W) {
+  if (!h) return DT_E_NULL;
+  return use_fused(h, H, W) ? 1 : 0;
+}
+
 /* test / report hook: the (bm, bn, splits) in use for block j, slot (0 skip, 1 conv1, 2 conv2) at a shape */
 int dt_unet_conv_choice(const dt_unet *h, int batch_total, int H, int W, int block, int slot, int *bm, int *bn,
                         int *splits, int *prec, int *tuned) {
@@ -850,6 +971,25 @@ static int sample_loop(const dt_unet *h, int rule, int B, int n_pass, int H, int
   if (Bt % tb_div) return DT_E_ARG;
   const int tb_rows = Bt / tb_div;         // time-bias rows per step
   if (make_plan(h, Bt, H, W).total * sizeof(float) > ws_bytes) return DT_E_WORKSPACE;
+  if (use_fused(h, H, W)) {
+    // small model: forward + CFG mix + update of up to kFusedMaxSteps timesteps per launch, images resident in LDS
+    for (int i0 = 0; i0 < n_steps; i0 += kFusedMaxSteps) {
+      const int n = n_steps - i0 < kFusedMaxSteps ? n_steps - i0 : kFusedMaxSteps;
+      FusedArgs a{};
+      fused_common(h, a, B, n_pass, B_single, tb + (size_t)i0 * tb_rows * h->tb_stride, tb_div);
+      a.mode = FUSED_LOOP; a.rule = rule; a.n_steps = n;
+      a.traj = traj + (size_t)i0 * slot; a.z = z; a.z_row = z_row; a.wg = w; a.w_scalar = w_scalar;
+      for (int i = 0; i < n; ++i) {
+        a.coef[i][0] = coef[4 * (i0 + i)]; a.coef[i][1] = coef[4 * (i0 + i) + 1]; a.coef[i][2] = coef[4 * (i0 + i) + 2];
+        a.z_shift[i] = z_shift ? (long long)z_shift[i0 + i] : 0;
+        if (has_noise[i0 + i]) a.noise_mask |= 1ull << i;
+        if (has_noise[i0 + i] && !z) return DT_E_NULL;
+      }
+      const int st = launch_unet_fused(a, s);
+      if (st) return st;
+    }
+    return DT_OK;
+  }
   const float *lowres = (const float *)ws + lowres_offset(h, Bt, H, W);
   (void)eps_scratch;                       // kept in the ABI: callers still hand in the scratch the unfused path used
   for (int i = 0; i < n_steps; ++i) {

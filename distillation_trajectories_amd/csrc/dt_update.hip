@@ -10,7 +10,7 @@
 // read(s).  All arithmetic is plain fp32 operators with fma contraction switched off, in the
 // reference's operation order: equal inputs give bit-identical outputs to torch CPU.
 // (HIP's __fmul_rn/__fadd_rn are header inlines compiled with contraction on, so they are not used.)
-#include "dt_internal.h"
+#include "dt_update_math.h"
 
 #pragma clang fp contract(off)
 
@@ -24,26 +24,13 @@ struct UpdateArgs {
   const int32_t *z_row;
   const float *w;
   float *out;
-  float c0, c1, c2, w_scalar;
+  StepCoef k;          // the step's three coefficients (dt_update_math.h)
+  float w_scalar;
   long long z_shift;   // added to the z row index (rows of E floats)
   int has_noise, B, E4;
   int lh, lw, hw;
   int b_single;        // rows [0, b_single) take the first prediction as it is (single-pass images of a mixed batch)
 };
-
-template <int RULE>
-__device__ inline float step1(float x, float eps, float z, const UpdateArgs &a, bool noise) {
-  if (RULE == DT_RULE_ENGINE) {
-    const float v = a.c0 * x - a.c1 * eps;
-    return v + a.c2 * z;
-  } else if (RULE == DT_RULE_PSAMPLE) {
-    const float v = a.c0 * (x - a.c1 * eps);
-    return v + (noise ? z * a.c2 : 0.f * a.c2);
-  } else {
-    const float v = (x - a.c0 * eps) / a.c1;       // IEEE division (hipcc's default for fp32 '/')
-    return v + a.c2 * z;
-  }
-}
 
 // eps of element (b, c, y, x..x+3) from a low-resolution head output (same arithmetic as head_upsample_kernel)
 __device__ inline float4 eps_from_lowres(const float *lowres, int b, int e, const UpdateArgs &a) {
@@ -97,11 +84,11 @@ __global__ __launch_bounds__(256) void cfg_update_kernel(const UpdateArgs a) {
     float4 o;
     if (RULE != DT_RULE_PSAMPLE && !noise) {
       // MANAGER at t == 0 never reaches the update in the reference; keep the deterministic part
-      o.x = step1<RULE>(xv.x, ev.x, 0.f, a, false); o.y = step1<RULE>(xv.y, ev.y, 0.f, a, false);
-      o.z = step1<RULE>(xv.z, ev.z, 0.f, a, false); o.w = step1<RULE>(xv.w, ev.w, 0.f, a, false);
+      o.x = step1<RULE>(xv.x, ev.x, 0.f, a.k, false); o.y = step1<RULE>(xv.y, ev.y, 0.f, a.k, false);
+      o.z = step1<RULE>(xv.z, ev.z, 0.f, a.k, false); o.w = step1<RULE>(xv.w, ev.w, 0.f, a.k, false);
     } else {
-      o.x = step1<RULE>(xv.x, ev.x, zv.x, a, noise); o.y = step1<RULE>(xv.y, ev.y, zv.y, a, noise);
-      o.z = step1<RULE>(xv.z, ev.z, zv.z, a, noise); o.w = step1<RULE>(xv.w, ev.w, zv.w, a, noise);
+      o.x = step1<RULE>(xv.x, ev.x, zv.x, a.k, noise); o.y = step1<RULE>(xv.y, ev.y, zv.y, a.k, noise);
+      o.z = step1<RULE>(xv.z, ev.z, zv.z, a.k, noise); o.w = step1<RULE>(xv.w, ev.w, zv.w, a.k, noise);
     }
     o4[i] = o;
   }
@@ -113,7 +100,7 @@ int launch_cfg_update(int rule, const float *x, const float *eu, const float *ec
   if (!x || !eu || !out || !coef) return DT_E_NULL;
   if (has_noise && !z) return DT_E_NULL;
   if (B <= 0 || E <= 0 || E % 4) return DT_E_SHAPE;
-  UpdateArgs a{x, eu, ec, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4, 0, 0, 0, 0};
+  UpdateArgs a{x, eu, ec, z, z_row, w, out, {coef[0], coef[1], coef[2]}, w_scalar, z_shift, has_noise, B, E / 4, 0, 0, 0, 0};
   const size_t total = (size_t)B * (E / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   // algorithmic bytes: read x + read z + write x' = 3*E*4 per sample-step (+ eps reads)
@@ -139,7 +126,7 @@ int launch_cfg_update_lowres(int rule, const float *x, const float *lowres_u, co
   const int E = C * H * W;
   if (B <= 0 || E <= 0 || W % 4 || H % 2 || W % 2) return DT_E_SHAPE;
   if (b_single < 0 || b_single > B) return DT_E_ARG;
-  UpdateArgs a{x, lowres_u, lowres_c, z, z_row, w, out, coef[0], coef[1], coef[2], w_scalar, z_shift, has_noise, B, E / 4,
+  UpdateArgs a{x, lowres_u, lowres_c, z, z_row, w, out, {coef[0], coef[1], coef[2]}, w_scalar, z_shift, has_noise, B, E / 4,
                H / 2, W / 2, H * W, b_single};
   const size_t total = (size_t)B * (E / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -109,6 +109,17 @@ import weakref
 
 _HANDLES = weakref.WeakKeyDictionary()      # nn.Module -> (weights key, UNetHandle)
 _TRAIN_WARNED = weakref.WeakSet()
+_FUSED_DEFAULT = True
+
+
+def set_fused_default(on):
+    """Whether small models (padded dims <= 32 / 64) at 16x16 take the fused whole-forward kernel (dt_fused.hip): applies to
+    every handle cached on a module and to handles created later.  ``DT_NO_FUSED=1`` in the environment is the same switch
+    at library level (read when a handle is created)."""
+    global _FUSED_DEFAULT
+    _FUSED_DEFAULT = bool(on)
+    for _, h in list(_HANDLES.values()):
+        h.set_fused(_FUSED_DEFAULT)
 
 
 class UNetHandle:
@@ -145,6 +156,8 @@ class UNetHandle:
         self._ws = {}
         self._consts = {}
         self._plans = {}              # (rows, H, W, images, single-pass images) -> plan id ("table:<sha1>", "tuned:<sha1>", "heuristic", "pinned")
+        if not _FUSED_DEFAULT:
+            self.set_fused(False)
 
     def __del__(self):
         try:
@@ -201,6 +214,14 @@ class UNetHandle:
         self._mode = {0: "fp32", 1: "split-bf16", 2: "auto"}[int(mode)]
         self._plans.clear()               # the library drops its tuned shapes too: choices are per arithmetic mode
 
+    def set_fused(self, on):
+        """Small models at 16x16: whole forward / whole sampler loop as one launch (dt_unet_set_fused); no-op for models
+        that do not qualify."""
+        check(self.lib.dt_unet_set_fused(self.h, int(bool(on))), "dt_unet_set_fused")
+
+    def fused_active(self, H, W):
+        return bool(self.lib.dt_unet_fused_active(self.h, H, W))
+
     def set_head_fusion(self, on):
         """Test hook (dt_unet_set_head_fusion): off = separate head launch, dec1's output is materialised."""
         check(self.lib.dt_unet_set_head_fusion(self.h, int(bool(on))), "dt_unet_set_head_fusion")
@@ -210,8 +231,12 @@ class UNetHandle:
         """{(rows, H, W)} of the shapes that run a table / measured / pinned plan (not the bare heuristic)."""
         return {k[:3] for k, v in self._plans.items() if v != "heuristic"}
 
+    # version of the launch-plan vocabulary (tile sizes, launch kinds, split semantics of dt_unet_set_conv_choice): the committed
+    # table and recorded caches stay valid across ABI revisions that only ADD entry points (ABI 4 added the fused-path switches)
+    PLAN_VERSION = 3
+
     def plan_key(self, rows, H, W, imgs, single):
-        return (f"abi{_hip.ABI_VERSION}|gfx950|prec={self._mode}|enc1={'shared' if self._shared_enc1 else 'per-pass'}|C{self.channels}"
+        return (f"abi{self.PLAN_VERSION}|gfx950|prec={self._mode}|enc1={'shared' if self._shared_enc1 else 'per-pass'}|C{self.channels}"
                 f"|D{self.temb_dim}|{','.join(map(str, self.dims))}|{rows}x{H}x{W}|{imgs}/{single}")
 
     def _read_plan(self, rows, H, W):
@@ -275,9 +300,11 @@ class UNetHandle:
         return {f"{k[0]}x{k[1]}x{k[2]} {k[3]}/{k[4]}": v for k, v in sorted(self._plans.items())}
 
     def set_conv_choice(self, batch_total, H, W, block, slot, bm, bn, splits=1, prec=1, fuse=0):
-        """Pin one convolution's launch choice for this forward shape (dt_unet_set_conv_choice)."""
+        """Pin one convolution's launch choice for this forward shape (dt_unet_set_conv_choice).  A launch pinned by hand asks
+        for the layered kernels, so the handle leaves the fused small-model path (``set_fused(True)`` returns to it)."""
         check(self.lib.dt_unet_set_conv_choice(self.h, batch_total, H, W, block, slot, bm, bn, splits, prec, fuse),
               "dt_unet_set_conv_choice")
+        self.set_fused(False)
         for k in [k for k in self._plans if k[:3] == (batch_total, H, W)]:
             self._plans[k] = "pinned"
         self._pinned = getattr(self, "_pinned", set()) | {(batch_total, H, W)}

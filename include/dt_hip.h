@@ -30,8 +30,9 @@ extern "C" {
  * in the conv-choice hooks; the exported symbols are those of version 1
  * 3: + dt_unet_forward_mixed / dt_sample_trajectory_mixed (single-pass and CFG images in one batch), dt_unet_declare_shape,
  *    dt_resize_bilinear;
- *    dt_sample_trajectory accepts eps_scratch_dev == NULL */
-#define DT_ABI_VERSION 3
+ *    dt_sample_trajectory accepts eps_scratch_dev == NULL
+ * 4: + dt_unet_set_fused / dt_unet_fused_active (small models: one launch per forward / per sampler call) */
+#define DT_ABI_VERSION 4
 
 enum {
   DT_OK = 0,
@@ -169,6 +170,15 @@ int dt_unet_set_precision(dt_unet *h, int precision);
  * and enc1.conv2 writes only its pooled output (nothing else reads enc1's full-resolution tensor); on = 0 materialises
  * both block outputs (separate head launch) so that dt_unet_debug_activation can expose every block */
 int dt_unet_set_head_fusion(dt_unet *h, int on);
+
+/* Small models (padded dims[0] <= 32, dims[1..3] <= 64: size factors <= 0.25 of models.py:104-110) at 16 x 16 run their
+ * WHOLE forward -- and dt_sample_trajectory(_mixed) their whole loop: forward, CFG mix, update and trajectory store of
+ * every timestep -- as ONE kernel launch with all activations in LDS, on the exact fp32 MFMA.  On by default where the
+ * model qualifies (DT_NO_FUSED=1 in the environment at create time: off); dt_unet_set_fused(h, 0) and
+ * dt_unet_set_head_fusion(h, 0) select the layered kernels for the handle (the per-layer launch choices above only
+ * concern those).  dt_unet_fused_active: 1 / 0 for an H x W image. */
+int dt_unet_set_fused(dt_unet *h, int on);
+int dt_unet_fused_active(const dt_unet *h, int H, int W);
 
 /* test hook: float offset / padded channel count of a block output inside the workspace
  * (which: 0..7 block outputs in DT order), valid after dt_unet_forward with the same shape */

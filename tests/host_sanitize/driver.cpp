@@ -103,6 +103,22 @@ int main() {
   CHECK(dt_unet_forward_mixed(h, x, B, 2, H, W, tb_mixed, 2, eps, ws, ws_bytes, s), DT_OK);            // 2 single-pass + 4 CFG images = 10 rows
   CHECK(dt_unet_forward_mixed(h, x, B, 3, H, W, tb_mixed, 2, eps, ws, ws_bytes, s), DT_E_ARG);         // tb_div must divide the single-pass count
   HIP(hipStreamSynchronize(s));
+  // ---- the model qualifies for the fused whole-forward kernel (padded dims 32 / 48): the calls above ran through it; a short
+  // sampler loop of each kind does too, then the layered kernels take over for the plan / tuning walk below
+  if (dt_unet_fused_active(h, H, W) != 1 || dt_unet_fused_active(h, 32, 32) != 0) { fprintf(stderr, "fused path not active\n"); return 1; }
+  CHECK(dt_unet_set_fused(nullptr, 1), DT_E_NULL);
+  {
+    float *ftraj = dev_random((size_t)3 * B * E, -1.f, 1.f), *fz = dev_random((size_t)2 * B * E, -1.f, 1.f), *fw = dev_random(B, 1.f, 7.f);
+    const float fcoef[8] = {0.5f, 0.5f, 0.5f, 0.f, 0.5f, 0.5f, 0.5f, 0.f};
+    const int32_t fnoise[2] = {1, 0};
+    const int64_t fshift[2] = {0, B};
+    CHECK(dt_sample_trajectory(h, DT_RULE_ENGINE, B, 2, H, W, 2, tb, fcoef, fnoise, fz, nullptr, fshift, fw, 1.f, ftraj, nullptr, ws, ws_bytes, s), DT_OK);
+    CHECK(dt_sample_trajectory(h, DT_RULE_PSAMPLE, B, 1, H, W, 2, tb, fcoef, fnoise, fz, nullptr, fshift, nullptr, 1.f, ftraj, nullptr, ws, ws_bytes, s), DT_OK);
+    CHECK(dt_sample_trajectory_mixed(h, DT_RULE_MANAGER, B, 2, H, W, 2, tb_mixed, 2, fcoef, fnoise, fz, nullptr, fshift, fw, ftraj, ws, ws_bytes, s), DT_OK);
+    HIP(hipStreamSynchronize(s));
+  }
+  CHECK(dt_unet_set_fused(h, 0), DT_OK);
+  if (dt_unet_fused_active(h, H, W) != 0) { fprintf(stderr, "fused path still active\n"); return 1; }
   // ---- plans: report, pin, declare, autotune, time one launch
   for (int blk = 0; blk < 8; ++blk)
     for (int slot = 0; slot < 3; ++slot) {

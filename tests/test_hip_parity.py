@@ -36,6 +36,15 @@ def gpu_models(models):
     return get
 
 
+@pytest.fixture(params=["fused", "layered"])
+def conv_path(request):
+    """The small models of the golden vectors (sf 0.01 / 0.2 at 16x16) run the fused whole-forward kernel by default; the
+    tests that carry this fixture also run them through the layered kernels, which serve every other shape."""
+    engine.set_fused_default(request.param == "fused")
+    yield request.param
+    engine.set_fused_default(True)
+
+
 def assert_close(got, want, rtol=1e-4, atol=2e-5, what=""):
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     err = np.abs(got - want)
@@ -61,7 +70,7 @@ def test_no_cpu_fallback(models):
 
 
 # ------------------------------------------------------------------ U-Net forward
-def test_unet_forward_golden(golden, gpu_models):
+def test_unet_forward_golden(golden, gpu_models, conv_path):
     arrays, meta = golden
     for c in meta["forward_cases"]:
         x = seeded_noise(c["seed"], (c["b"], 3, c["h"], c["h"]))
@@ -443,7 +452,7 @@ def test_cfg_update_per_row_scale_and_noise_rows():
 
 
 # ------------------------------------------------------------------ whole loops vs golden
-def test_engine_trajectories_golden(golden, gpu_models):
+def test_engine_trajectories_golden(golden, gpu_models, conv_path):
     from distillation_trajectories_amd.analysis.trajectory_engine import generate_trajectory
     arrays, meta = golden
     for c in meta["engine_cases"]:
@@ -459,7 +468,7 @@ def test_engine_trajectories_golden(golden, gpu_models):
         assert_close(got, arrays[c["key"]], rtol=1e-4, atol=1e-4, what=str(c))
 
 
-def test_psample_loops_golden(golden, gpu_models):
+def test_psample_loops_golden(golden, gpu_models, conv_path):
     from distillation_trajectories_amd.utils.diffusion import get_diffusion_params, p_sample_loop
     arrays, meta = golden
     for c in meta["psample_cases"]:
@@ -506,7 +515,7 @@ def _check_metrics(got, want, rel=1e-4, skip=()):
             assert_close(float(g), float(w), rtol=rel, atol=1e-9, what=k)
 
 
-def test_manager_golden(golden, gpu_models, tmp_path):
+def test_manager_golden(golden, gpu_models, tmp_path, conv_path):
     from distillation_trajectories_amd.analysis.metrics.trajectory_metrics import compute_trajectory_metrics
     from distillation_trajectories_amd.utils.trajectory_manager import TrajectoryManager
     arrays, meta = golden
@@ -575,7 +584,7 @@ def test_metrics_device_inputs_and_tuples(golden):
     _check_metrics(compute_trajectory_metrics(a, b), c["metrics"], rel=2e-5, skip=("trajectory_mse",))
 
 
-def test_compare_trajectories_golden(golden, gpu_models):
+def test_compare_trajectories_golden(golden, gpu_models, conv_path):
     from distillation_trajectories_amd.analysis.trajectory_engine import compare_trajectories
     _, meta = golden
     c = meta["compare_case"]
