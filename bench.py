@@ -237,8 +237,8 @@ class PairWorkload:
             if len(ps) > 1:                      # reassemble [T+1, B, E] for the pairwise metrics
                 torch.cat(self.part_traj[i], dim=1, out=self.traj[i])
         t_gpu0 = time.perf_counter() if os.environ.get("DT_BENCH_TIMING") else 0.0
-        sums = eng.device_metric_sums(self.traj[0], self.traj[1])          # [B, T+1, 4] float64
-        w1 = eng.device_wasserstein(self.traj[0], self.traj[1], self.w_index, self.w_rows)   # [B, T+1] float64
+        # [B, T+1, 4] and [B, T+1] float64: one launch (dt_traj_pair_metrics) when all E <= 1000 coordinates are sampled
+        sums, w1 = eng.device_pair_metrics(self.traj[0], self.traj[1], self.w_index, self.w_rows)
         local = torch.cat([sums.reshape(self.B, -1), w1], dim=1)
         full = all_gather_rows(local, counts, dim=0, force=True) if (world > 1 or self.collective) else local
         host = full.cpu().numpy()                                          # syncs the stream
@@ -481,10 +481,9 @@ def tame_pair_delta(spec, wl, device, scale=0.01):
             k += int(flag)
         h.sample(RULE_PSAMPLE, traj, H, H, tb, 2, wl.coef, wl.has_noise, z=zz, z_shift=shift, w_scalar=spec["guidance"])
         trajs.append(traj)
-    sums = engine.device_metric_sums(trajs[0], trajs[1])
-    w1 = engine.device_wasserstein(trajs[0], trajs[1], None, None) if wl.E <= 1000 else None
-    if w1 is None:
+    if wl.E > 1000:
         return None
+    sums, w1 = engine.device_pair_metrics(trajs[0], trajs[1])
     host = torch.cat([sums.reshape(B, -1), w1], dim=1).cpu().numpy()
     n = T + 1
     vals = engine.batch_scalar_metrics(host[:, : 4 * n].reshape(-1, n, 4), host[:, 4 * n:], H * H, wl.E)

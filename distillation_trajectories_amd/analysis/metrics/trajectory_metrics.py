@@ -94,15 +94,16 @@ def compute_trajectory_metrics_many(pairs, config=None):
         # [n, P, E]: every list entry [B,C,H,W] is ONE point of a trajectory (the reference's norms run over the whole entry)
         Xd = torch.stack([_stack_on_device(prepared[k][0], device)[:, 0] for k in members], dim=1).contiguous()
         Yd = torch.stack([_stack_on_device(prepared[k][1], device)[:, 0] for k in members], dim=1).contiguous()
-        parts = [engine.device_metric_sums(Xd, Yd).reshape(P, -1)]
-        if nT != nS:
-            longer, shorter = (Xd, Yd) if nT > nS else (Yd, Xd)
-            parts.append(engine.device_resampled_distance(longer, shorter))
         index = index_row = None
         if E > 1000:
             index = torch.from_numpy(np.stack([np.stack(prepared[k][5]) for k in members]).astype(np.int32)).to(device)
             index_row = torch.arange(P, dtype=torch.int32, device=device)
-        parts.append(engine.device_wasserstein(Xd, Yd, index, index_row))
+        sums_d, w1_d = engine.device_pair_metrics(Xd, Yd, index, index_row)   # one launch for equal lengths and E <= 1000
+        parts = [sums_d.reshape(P, -1)]
+        if nT != nS:
+            longer, shorter = (Xd, Yd) if nT > nS else (Yd, Xd)
+            parts.append(engine.device_resampled_distance(longer, shorter))
+        parts.append(w1_d)
         host = torch.cat(parts, dim=1).cpu().numpy()                 # the one device-to-host copy of the group
         n_max = max(nT, nS)
         pixels = shape[2] * shape[3]

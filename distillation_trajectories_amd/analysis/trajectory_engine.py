@@ -200,12 +200,12 @@ def pair_metrics_device(X, Y, pixels, seeds=None):
     from .metrics.trajectory_metrics import wasserstein_index_tables
     n, B, E = X.shape
     Xc, Yc = X.contiguous(), Y.contiguous()
-    sums = engine.device_metric_sums(Xc, Yc).cpu().numpy()
     index = index_row = None
     if E > 1000:
         tables, index_row = wasserstein_index_tables(seeds, n, E)
         index, index_row = tables.to(X.device), index_row.to(X.device)
-    w1 = engine.device_wasserstein(Xc, Yc, index, index_row).cpu().numpy()
+    sums, w1 = engine.device_pair_metrics(Xc, Yc, index, index_row)      # one launch when all coordinates are sampled
+    sums, w1 = sums.cpu().numpy(), w1.cpu().numpy()
     return [engine.metrics_from_sums(sums[b], w1[b], n, n, pixels, E) for b in range(B)]
 
 

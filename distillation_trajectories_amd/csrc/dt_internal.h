@@ -26,7 +26,7 @@ enum KernelClass {
   KC_CONVB_128x128, KC_CONVB_128x64, KC_CONVB_64x128, KC_CONVB_64x64,
   KC_CONVS_128x128, KC_CONVS_128x64, KC_CONVS_64x128, KC_CONVS_64x64, KC_CONVS_256x64, KC_CONVS_K128x64, KC_CONVS_K64x64, KC_CONVS_K64x128,
   KC_SPLITK_EPILOGUE, KC_FIRST_CONV, KC_POOL, KC_UPCAT, KC_HEAD, KC_HEAD_UP, KC_TIME_BIAS, KC_UPDATE, KC_METRICS,
-  KC_WASSERSTEIN, KC_RESAMPLE, KC_FUSED,
+  KC_WASSERSTEIN, KC_RESAMPLE, KC_FUSED, KC_PAIR_METRICS,
   KC_COUNT
 };
 struct ProfileScope {

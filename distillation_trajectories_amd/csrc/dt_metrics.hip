@@ -207,6 +207,129 @@ int launch_wasserstein(const float *X, const float *Y, int n, int B, int E, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// One pass over a pair's states for BOTH reductions above (equal lengths, all E <= 4096 coordinates sampled: every
+// 16x16 and 32x32 configuration whose Wasserstein term uses all coordinates).  A workgroup owns (pair b, step i): thread t
+// holds coordinates t R .. t R + R - 1 of X_i and Y_i in registers (one or more 16-byte loads), forms the four sums
+// against X_{i-1}, Y_{i-1} (the same workgroup order makes that second read an L2 hit: consecutive workgroups are
+// consecutive steps of one pair, so a state comes from HBM once) and then sorts its two register arrays IN PLACE with a
+// bitonic network whose exchanges are, by distance j between partners:
+//   j < R        the thread's own registers,
+//   j < 64 R     a lane of the same wavefront: __shfl_xor (64-lane cross-lane network, no LDS storage, no barrier),
+//   j >= 64 R    another wavefront: through LDS (three of the 55 stages at N = 1024).
+// The LDS bitonic sort of wasserstein_kernel runs all 55 stages (110 per pair-step) through LDS behind a barrier each:
+// 479 us per 256 x 51 pair-steps against 35 us for the sums; this kernel does both in one launch.
+// W1 = mean_k |u_(k) - v_(k)|: both arrays end in the same (ascending) layout, so the sum is thread-local.
+template <int R>
+__global__ __launch_bounds__(256) void pair_metrics_kernel(const float *__restrict__ X, const float *__restrict__ Y, int n, int B,
+                                                           int E, double *__restrict__ out_sums, double *__restrict__ out_w1) {
+  constexpr int N = 256 * R;
+  __shared__ float ex[2][N];
+  __shared__ double sm[20];
+  const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const size_t step = (size_t)B * E;
+  const int j0 = i >= 1 ? i - 1 : n - 1;               // i == 0: the trajectory's own last state (endpoint terms)
+  const float *x = X + i * step + (size_t)b * E, *y = Y + i * step + (size_t)b * E;
+  const float *px = X + j0 * step + (size_t)b * E, *py = Y + j0 * step + (size_t)b * E;
+  float u[R], v[R];
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < R / 4; ++q) {
+    const int e = tid * R + q * 4;
+    float4 a = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()), c = a;
+    if (e < E) {                                        // E % 4 == 0: a quad is inside or outside as a whole
+      a = *reinterpret_cast<const float4 *>(x + e); c = *reinterpret_cast<const float4 *>(y + e);
+      const float4 pa = *reinterpret_cast<const float4 *>(px + e), pc = *reinterpret_cast<const float4 *>(py + e);
+      const float av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w};
+      const float pv[4] = {pa.x, pa.y, pa.z, pa.w}, qv[4] = {pc.x, pc.y, pc.z, pc.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // differences in fp32 exactly as torch forms (X_i - Y_i) before the norm; float64 accumulation (traj_metrics_kernel)
+        const float d = av[k] - cv[k], dx = av[k] - pv[k], dy = cv[k] - qv[k], de = pv[k] - qv[k];
+        acc[0] += (double)d * (double)d;
+        acc[1] += (double)dx * (double)dx;
+        acc[2] += (double)dy * (double)dy;
+        acc[3] += i >= 1 ? (double)dx * (double)dy : (double)de * (double)de;
+      }
+    }
+    u[q * 4] = a.x; u[q * 4 + 1] = a.y; u[q * 4 + 2] = a.z; u[q * 4 + 3] = a.w;
+    v[q * 4] = c.x; v[q * 4 + 1] = c.y; v[q * 4 + 2] = c.z; v[q * 4 + 3] = c.w;
+  }
+  // ---- bitonic sort of element e = tid R + r, ascending; +inf padding sorts to the tail of both arrays.  Exchanges are
+  // compare-and-select on (lower > upper), as in bitonic_sort above: a NaN stays in the array (the term becomes NaN, like the
+  // reference's), which fminf / fmaxf would silently drop.
+  auto exchange = [](float &mine, float other, bool i_am_lower, bool up) __attribute__((always_inline)) {
+    const bool gt = i_am_lower ? mine > other : other > mine;      // (value at the lower index) > (value at the upper index)
+    if (gt == up) mine = other;
+  };
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j >= R; j >>= 1) {             // partners in other threads
+      if (j < 64 * R) {
+        const int d = j / R;                            // lane distance
+        const bool lower = (lane & d) == 0;             // this thread holds the lower index of every pair
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const bool up = ((tid * R + r) & k) == 0;
+          const float uo = __shfl_xor(u[r], d, 64), vo = __shfl_xor(v[r], d, 64);
+          exchange(u[r], uo, lower, up);
+          exchange(v[r], vo, lower, up);
+        }
+      } else {
+        const int dt = j / R;                           // thread distance (a multiple of 64)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ex[0][r * 256 + tid] = u[r]; ex[1][r * 256 + tid] = v[r]; }
+        __syncthreads();
+        const bool lower = (tid & dt) == 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const bool up = ((tid * R + r) & k) == 0;
+          exchange(u[r], ex[0][r * 256 + (tid ^ dt)], lower, up);
+          exchange(v[r], ex[1][r * 256 + (tid ^ dt)], lower, up);
+        }
+      }
+    }
+    // partners inside the thread: j = R/2 .. 1 as COMPILE-TIME constants (a run-time j would index the register arrays
+    // dynamically, i.e. move them to scratch memory)
+#pragma unroll
+    for (int j = R / 2; j > 0; j >>= 1) {
+      if (j < k) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & j) == 0) {
+            const bool up = ((tid * R + r) & k) == 0;
+            const float u0 = u[r], u1 = u[r | j], v0 = v[r], v1 = v[r | j];
+            if ((u0 > u1) == up) { u[r] = u1; u[r | j] = u0; }
+            if ((v0 > v1) == up) { v[r] = v1; v[r | j] = v0; }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (tid * R + r < E) acc[4] += fabs((double)u[r] - (double)v[r]);
+  block_sum<5>(acc, sm);
+  if (tid == 0) {
+    double *o = out_sums + ((size_t)b * n + i) * 4;
+    o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    out_w1[(size_t)b * n + i] = acc[4] / (double)E;
+  }
+}
+
+int launch_pair_metrics(const float *X, const float *Y, int n, int B, int E, double *out_sums, double *out_w1, hipStream_t s) {
+  if (!X || !Y || !out_sums || !out_w1) return DT_E_NULL;
+  if (n < 1 || B < 1 || E < 4 || E % 4 || E > 4096 || n > 65535 || B > 65535) return DT_E_SHAPE;
+  // algorithmic bytes: one read of both trajectories (2 (T+1) E 4 per pair)
+  ProfileScope prof(KC_PAIR_METRICS, 0.0, 8.0 * B * E * (double)n, s);
+  const dim3 grid(n, B);                                // x = step: consecutive workgroups share a state through L2
+  if (E <= 1024) pair_metrics_kernel<4><<<grid, 256, 0, s>>>(X, Y, n, B, E, out_sums, out_w1);
+  else if (E <= 2048) pair_metrics_kernel<8><<<grid, 256, 0, s>>>(X, Y, n, B, E, out_sums, out_w1);
+  else pair_metrics_kernel<16><<<grid, 256, 0, s>>>(X, Y, n, B, E, out_sums, out_w1);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // trajectory_metrics.py:239-279: the longer trajectory L (n_long states) is resampled by linear
 // interpolation (scipy interp1d, float64) onto the shorter's grid linspace(0,1,n_short); output is
 // |L'(t_i) - S_i|_2 per (pair, i) in float64, as numpy computes it on the float64 resampled points.

@@ -30,6 +30,7 @@ int launch_wasserstein(const float *X, const float *Y, int n, int B, int E, cons
                        const int32_t *index_row, int n_idx, double *out, hipStream_t s);
 int launch_resampled_distance(const float *L, const float *S, int n_long, int n_short, int B, int E, double *out,
                               hipStream_t s);
+int launch_pair_metrics(const float *X, const float *Y, int n, int B, int E, double *out_sums, double *out_w1, hipStream_t s);
 int launch_pair_stats(const float *X, const float *Y, int n, int B, int E, double *out, hipStream_t s);
 int launch_sample_mean(const float *traj, int n, int B, int E, float *out, hipStream_t s);
 int launch_resize_bilinear(const float *in, float *out, int planes, int h, int w, int H, int W, hipStream_t s);
@@ -63,7 +64,7 @@ const char *kClassName[KC_COUNT] = {
     "conv_strip_bf16x6_kernel<64,64>", "conv_strip_bf16x6_kernel<256,64>", "conv_strip_bf16x6_kernel<128,64,K2>",
     "conv_strip_bf16x6_kernel<64,64,K4>", "conv_strip_bf16x6_kernel<64,128,K2>", "splitk_epilogue_kernel", "first_conv_kernel", "maxpool_kernel", "upcat_kernel", "head_kernel", "head_upsample_kernel",
     "time_bias_kernel", "cfg_update_kernel", "traj_metrics_kernel", "wasserstein_kernel", "resampled_distance_kernel",
-    "unet_fused_kernel"};
+    "unet_fused_kernel", "pair_metrics_kernel"};
 }  // namespace
 
 namespace dt {
@@ -1124,6 +1125,10 @@ int dt_traj_metrics(const float *X, const float *Y, int nT, int nS, int B, int E
 int dt_traj_wasserstein(const float *X, const float *Y, int n, int B, int E, const int32_t *index,
                         const int32_t *index_row, int n_idx, double *out, void *stream) {
   return launch_wasserstein(X, Y, n, B, E, index, index_row, n_idx, out, (hipStream_t)stream);
+}
+
+int dt_traj_pair_metrics(const float *X, const float *Y, int n, int B, int E, double *out_sums, double *out_w1, void *stream) {
+  return launch_pair_metrics(X, Y, n, B, E, out_sums, out_w1, (hipStream_t)stream);
 }
 
 int dt_pair_stats(const float *X, const float *Y, int n, int B, int E, double *out, void *stream) {

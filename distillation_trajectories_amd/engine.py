@@ -500,6 +500,22 @@ def device_wasserstein(X, Y, index=None, index_row=None):
     return out
 
 
+def device_pair_metrics(X, Y, index=None, index_row=None):
+    """(sums float64 [B, n_max, 4], w1 float64 [B, min(n)]) of ``device_metric_sums`` and ``device_wasserstein`` -- in ONE
+    launch (dt_traj_pair_metrics: each state read from HBM once, register / cross-lane sort) when the trajectories have equal
+    lengths and the Wasserstein term uses all E <= 4096 coordinates, otherwise through the two separate kernels."""
+    lib = _hip.load()
+    _require_cuda(X, "teacher trajectory"); _require_cuda(Y, "student trajectory")
+    n, B, E = X.shape
+    if index is not None or Y.shape[0] != n or E > 4096 or E % 4 or B > 65535:
+        return device_metric_sums(X, Y), device_wasserstein(X, Y, index, index_row)
+    sums = torch.empty(B, n, 4, dtype=torch.float64, device=X.device)
+    w1 = torch.empty(B, n, dtype=torch.float64, device=X.device)
+    with torch.cuda.device(X.device):
+        check(lib.dt_traj_pair_metrics(ptr(X), ptr(Y), n, B, E, ptr(sums), ptr(w1), stream_ptr()), "dt_traj_pair_metrics")
+    return sums, w1
+
+
 def device_pair_stats(X, Y):
     """float64 [B, n, 5] = {sum (x-y)^2, sum |x-y|, sum xy, sum x^2, sum y^2} for X, Y [n, B, E] (dt_pair_stats)."""
     lib = _hip.load()

@@ -140,8 +140,7 @@ def hip_cell_metrics(teacher, students, cfg, guidance_scales, first_sample, coun
                         s_groups = sample_grid_groups(handles[1 + i], table, 0, count, T, scales, H, H, throttle=len(side) > 1)
                         parts = []
                         for (_, X, _), (_, Y, _), rows in zip(t_groups, s_groups, row_sets):
-                            sums = engine.device_metric_sums(X, Y)                       # [G*S, n, 4]
-                            w1 = engine.device_wasserstein(X, Y, index, rows)            # [G*S, n]
+                            sums, w1 = engine.device_pair_metrics(X, Y, index, rows)     # [G*S, n, 4], [G*S, n]: one launch at E <= 1000
                             parts.append(torch.cat([sums.reshape(X.shape[1], -1), w1], dim=1))
                         results[i] = torch.cat(parts, dim=0)
             except Exception as e:       # surfaced on the calling thread

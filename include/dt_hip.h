@@ -31,7 +31,8 @@ extern "C" {
  * 3: + dt_unet_forward_mixed / dt_sample_trajectory_mixed (single-pass and CFG images in one batch), dt_unet_declare_shape,
  *    dt_resize_bilinear;
  *    dt_sample_trajectory accepts eps_scratch_dev == NULL
- * 4: + dt_unet_set_fused / dt_unet_fused_active (small models: one launch per forward / per sampler call) */
+ * 4: + dt_unet_set_fused / dt_unet_fused_active (small models: one launch per forward / per sampler call),
+ *    dt_traj_pair_metrics (metric sums + Wasserstein term in one pass) */
 #define DT_ABI_VERSION 4
 
 enum {
@@ -238,6 +239,13 @@ int dt_traj_metrics(const float *teacher_dev, const float *student_dev, int nT, 
 int dt_traj_wasserstein(const float *teacher_dev, const float *student_dev, int n, int B, int E,
                         const int32_t *index_dev, const int32_t *index_row_dev, int n_idx,
                         double *out_w1_dev, void *stream);
+
+/* Both reductions above in ONE pass for two trajectories of equal length n whose Wasserstein term uses all E <= 4096
+ * coordinates (every 16 x 16 configuration): out_sums_dev[B][n][4] as dt_traj_metrics, out_w1_dev[B][n] as
+ * dt_traj_wasserstein(index NULL).  A workgroup per (pair, step) keeps both states in registers: the sums against the
+ * previous states, then a register / cross-lane (__shfl_xor) bitonic sort of both; each state comes from HBM once. */
+int dt_traj_pair_metrics(const float *teacher_dev, const float *student_dev, int n, int B, int E,
+                         double *out_sums_dev, double *out_w1_dev, void *stream);
 
 /* trajectory_metrics.py:239-279: linear (scipy interp1d, float64) resampling of the longer trajectory
  * onto the shorter's normalised time grid, then |L'(t_i) - S_i|_2 in float64.  out_dist_dev[B][n_short] */

@@ -171,6 +171,8 @@ int main() {
   CHECK(dt_traj_wasserstein(traj, traj, n_steps + 1, B, E, nullptr, nullptr, 0, sums, s), DT_OK);
   CHECK(dt_traj_resampled_distance(traj, traj, n_steps + 1, 3, B, E, sums, s), DT_OK);
   CHECK(dt_pair_stats(traj, traj, n_steps + 1, B, E, sums, s), DT_OK);
+  CHECK(dt_traj_pair_metrics(traj, traj, n_steps + 1, B, E, sums, sums + (size_t)B * (n_steps + 1) * 4, s), DT_OK);
+  CHECK(dt_traj_pair_metrics(traj, traj, n_steps + 1, B, 4100, sums, sums, s), DT_E_SHAPE);
   CHECK(dt_traj_sample_mean(traj, n_steps + 1, B, E, eps, s), DT_OK);
   CHECK(dt_resize_bilinear(x, eps, B * C, H, W, 8, 24, s), DT_OK);
   CHECK(dt_resize_bilinear(x, nullptr, B * C, H, W, 8, 24, s), DT_E_NULL);

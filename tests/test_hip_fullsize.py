@@ -445,3 +445,43 @@ def test_two_ranks_shard_the_grid_like_one(tmp_path):
     assert two["metric_check"]["cells"] == one["metric_check"]["cells"] == 11 * 4 * 6
     a, b = two["metric_check"]["path_length_similarity_sf0.5_gs3"], one["metric_check"]["path_length_similarity_sf0.5_gs3"]
     assert abs(a - b) <= 1e-6 * abs(b), (a, b)
+
+
+@pytest.mark.parametrize("shape", [(51, 256, 768), (7, 5, 1024), (4, 3, 1540), (3, 2, 3072), (2, 1, 4096), (5, 4, 12)])
+def test_one_pass_pair_metrics_match_the_two_kernels(shape):
+    """dt_traj_pair_metrics (sums + register / cross-lane bitonic sort in one launch) against dt_traj_metrics and
+    dt_traj_wasserstein (LDS sort): the sorted order statistics are the same numbers, so W1 agrees to float64 summation
+    order; E = 768 is every 16x16x3 configuration, 1540 / 3072 / 4096 exercise 8 and 16 coordinates per thread and the +inf
+    padding, 12 a nearly empty workgroup."""
+    n, B, E = shape
+    g = torch.Generator().manual_seed(n * 1000 + E)
+    X = (torch.randn(n, B, E, generator=g).cumsum(0) * 0.05).to(DEV)
+    Y = (X.cpu() + 0.02 * torch.randn(n, B, E, generator=g)).to(DEV)
+    sums, w1 = engine.device_pair_metrics(X, Y)
+    ref_s, ref_w = engine.device_metric_sums(X, Y), engine.device_wasserstein(X, Y)
+    assert sums.shape == ref_s.shape and w1.shape == ref_w.shape
+    assert torch.allclose(sums, ref_s, rtol=1e-12, atol=0), (sums - ref_s).abs().max()
+    assert torch.allclose(w1, ref_w, rtol=1e-12, atol=1e-18), (w1 - ref_w).abs().max()
+    # against numpy's own sort for one (pair, step)
+    u, v = np.sort(X[n - 1, B - 1].cpu().numpy()).astype(np.float64), np.sort(Y[n - 1, B - 1].cpu().numpy()).astype(np.float64)
+    assert abs(w1[B - 1, n - 1].item() - np.abs(u - v).mean()) <= 1e-12 * max(1.0, np.abs(u - v).mean())
+    same_s, same_w = engine.device_pair_metrics(X, X)
+    assert not same_w.cpu().numpy().any() and not same_s[..., 0].cpu().numpy().any()
+
+
+def test_one_pass_pair_metrics_keep_non_finite_states_in_their_cell():
+    """A NaN / Inf coordinate makes the terms of ITS (pair, step) and of the next step's differences non-finite, exactly where
+    the separate kernels put them, and nowhere else."""
+    n, B, E = 6, 4, 768
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(n, B, E, generator=g)
+    Y = torch.randn(n, B, E, generator=g)
+    X[2, 1, 100] = float("nan")
+    Y[4, 3, 7] = float("inf")
+    sums, w1 = engine.device_pair_metrics(X.to(DEV), Y.to(DEV))
+    ref_s, ref_w = engine.device_metric_sums(X.to(DEV), Y.to(DEV)), engine.device_wasserstein(X.to(DEV), Y.to(DEV))
+    assert torch.equal(torch.isfinite(sums), torch.isfinite(ref_s))
+    bad = ~torch.isfinite(w1)
+    assert torch.equal(bad, ~torch.isfinite(ref_w)) and bad[1, 2] and bad[3, 4] and bad.sum().item() == 2
+    ok = torch.isfinite(ref_s)
+    assert torch.allclose(sums[ok], ref_s[ok], rtol=1e-12, atol=0)
