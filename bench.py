@@ -496,10 +496,11 @@ def tame_pair_delta(spec, wl, device, scale=0.01):
     return delta
 
 
-def traffic_from_profiles(kernel_name):
+def traffic_from_profiles(kernel_name, config=1):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
     --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 note), or None if not recorded."""
-    for name in ("r02_hbm_traffic.json", "hbm_traffic.json"):
+    names = ("r03c2_hbm_traffic.json",) if config == 2 else ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "hbm_traffic.json")
+    for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 hit = json.load(f).get(kernel_name)
@@ -649,7 +650,7 @@ def main():
         split = "bf16x6" in dom_name
         peak = PEAK_BF16_MFMA_TFLOPS / PLANE_PRODUCTS if split else PEAK_FP32_MFMA_TFLOPS
         traffic = None
-        per = {n: traffic_from_profiles(n) for n in dom["members"]}
+        per = {n: traffic_from_profiles(n, args.config) for n in dom["members"]}
         if all(per.values()):
             traffic = {"hbm_bytes_per_launch": int(sum(per[n]["hbm_bytes_per_launch"] * k["launches"] for n, k in dom["members"].items())
                                                    / dom["launches"]),

@@ -223,15 +223,26 @@ template <int R>
 __global__ __launch_bounds__(256) void pair_metrics_kernel(const float *__restrict__ X, const float *__restrict__ Y, int n, int B,
                                                            int E, double *__restrict__ out_sums, double *__restrict__ out_w1) {
   constexpr int N = 256 * R;
-  __shared__ float ex[2][N];
+  __shared__ unsigned ex[2][N];
   __shared__ double sm[20];
   const int i = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const size_t step = (size_t)B * E;
   const int j0 = i >= 1 ? i - 1 : n - 1;               // i == 0: the trajectory's own last state (endpoint terms)
   const float *x = X + i * step + (size_t)b * E, *y = Y + i * step + (size_t)b * E;
   const float *px = X + j0 * step + (size_t)b * E, *py = Y + j0 * step + (size_t)b * E;
-  float u[R], v[R];
+  // The sort runs on order-preserving integer keys (sign-magnitude float bits -> unsigned: negative values are complemented,
+  // positive ones get the top bit): an exchange is then v_min_u32 + v_max_u32 + one select, three VALU instructions per
+  // element, against six for a float compare-and-swap that has to keep NaNs in place -- the kernel is VALU-bound (52 exchange
+  // stages x 8 elements per thread).  A NaN coordinate makes the step's term NaN, as in wasserstein_kernel / the reference:
+  // it is flagged while loading.
+  auto to_key = [](float f) __attribute__((always_inline)) {
+    const unsigned bits = __float_as_uint(f);
+    return bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);
+  };
+  auto from_key = [](unsigned k) __attribute__((always_inline)) { return __uint_as_float(k ^ (((k >> 31) - 1u) | 0x80000000u)); };
+  unsigned u[R], v[R];
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  bool has_nan = false;
 #pragma unroll
   for (int q = 0; q < R / 4; ++q) {
     const int e = tid * R + q * 4;
@@ -249,29 +260,26 @@ __global__ __launch_bounds__(256) void pair_metrics_kernel(const float *__restri
         acc[1] += (double)dx * (double)dx;
         acc[2] += (double)dy * (double)dy;
         acc[3] += i >= 1 ? (double)dx * (double)dy : (double)de * (double)de;
+        has_nan |= (av[k] != av[k]) || (cv[k] != cv[k]);
       }
     }
-    u[q * 4] = a.x; u[q * 4 + 1] = a.y; u[q * 4 + 2] = a.z; u[q * 4 + 3] = a.w;
-    v[q * 4] = c.x; v[q * 4 + 1] = c.y; v[q * 4 + 2] = c.z; v[q * 4 + 3] = c.w;
+    u[q * 4] = to_key(a.x); u[q * 4 + 1] = to_key(a.y); u[q * 4 + 2] = to_key(a.z); u[q * 4 + 3] = to_key(a.w);
+    v[q * 4] = to_key(c.x); v[q * 4 + 1] = to_key(c.y); v[q * 4 + 2] = to_key(c.z); v[q * 4 + 3] = to_key(c.w);
   }
-  // ---- bitonic sort of element e = tid R + r, ascending; +inf padding sorts to the tail of both arrays.  Exchanges are
-  // compare-and-select on (lower > upper), as in bitonic_sort above: a NaN stays in the array (the term becomes NaN, like the
-  // reference's), which fminf / fmaxf would silently drop.
-  auto exchange = [](float &mine, float other, bool i_am_lower, bool up) __attribute__((always_inline)) {
-    const bool gt = i_am_lower ? mine > other : other > mine;      // (value at the lower index) > (value at the upper index)
-    if (gt == up) mine = other;
-  };
+  // ---- bitonic sort of element e = tid R + r, ascending; +inf padding sorts to the tail of both arrays
   for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j >= R; j >>= 1) {             // partners in other threads
+      // this thread keeps the smaller key of each pair when it holds the lower index of an ascending pair (or the upper of a
+      // descending one); for k >= R the direction bit of an element does not depend on r
       if (j < 64 * R) {
         const int d = j / R;                            // lane distance
-        const bool lower = (lane & d) == 0;             // this thread holds the lower index of every pair
+        const bool lower = (lane & d) == 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const bool up = ((tid * R + r) & k) == 0;
-          const float uo = __shfl_xor(u[r], d, 64), vo = __shfl_xor(v[r], d, 64);
-          exchange(u[r], uo, lower, up);
-          exchange(v[r], vo, lower, up);
+          const bool keep_min = (((tid * R + r) & k) == 0) == lower;
+          const unsigned uo = __shfl_xor(u[r], d, 64), vo = __shfl_xor(v[r], d, 64);
+          u[r] = keep_min ? min(u[r], uo) : max(u[r], uo);
+          v[r] = keep_min ? min(v[r], vo) : max(v[r], vo);
         }
       } else {
         const int dt = j / R;                           // thread distance (a multiple of 64)
@@ -282,9 +290,10 @@ __global__ __launch_bounds__(256) void pair_metrics_kernel(const float *__restri
         const bool lower = (tid & dt) == 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const bool up = ((tid * R + r) & k) == 0;
-          exchange(u[r], ex[0][r * 256 + (tid ^ dt)], lower, up);
-          exchange(v[r], ex[1][r * 256 + (tid ^ dt)], lower, up);
+          const bool keep_min = (((tid * R + r) & k) == 0) == lower;
+          const unsigned uo = ex[0][r * 256 + (tid ^ dt)], vo = ex[1][r * 256 + (tid ^ dt)];
+          u[r] = keep_min ? min(u[r], uo) : max(u[r], uo);
+          v[r] = keep_min ? min(v[r], vo) : max(v[r], vo);
         }
       }
     }
@@ -297,9 +306,9 @@ __global__ __launch_bounds__(256) void pair_metrics_kernel(const float *__restri
         for (int r = 0; r < R; ++r) {
           if ((r & j) == 0) {
             const bool up = ((tid * R + r) & k) == 0;
-            const float u0 = u[r], u1 = u[r | j], v0 = v[r], v1 = v[r | j];
-            if ((u0 > u1) == up) { u[r] = u1; u[r | j] = u0; }
-            if ((v0 > v1) == up) { v[r] = v1; v[r | j] = v0; }
+            const unsigned ul = min(u[r], u[r | j]), uh = max(u[r], u[r | j]), vl = min(v[r], v[r | j]), vh = max(v[r], v[r | j]);
+            u[r] = up ? ul : uh; u[r | j] = up ? uh : ul;
+            v[r] = up ? vl : vh; v[r | j] = up ? vh : vl;
           }
         }
       }
@@ -307,7 +316,8 @@ __global__ __launch_bounds__(256) void pair_metrics_kernel(const float *__restri
   }
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (tid * R + r < E) acc[4] += fabs((double)u[r] - (double)v[r]);
+    if (tid * R + r < E) acc[4] += fabs((double)from_key(u[r]) - (double)from_key(v[r]));
+  if (has_nan) acc[4] = __builtin_nan("");
   block_sum<5>(acc, sm);
   if (tid == 0) {
     double *o = out_sums + ((size_t)b * n + i) * 4;

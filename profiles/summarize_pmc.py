@@ -13,8 +13,9 @@ import collections, csv, glob, json, os, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
-METHOD = ("rocprofv3 --kernel-trace [--pmc ...] in separate passes over `bench.py --steps 2 --warmup 1 --serial` "
-          "(profiles/collect_%s.sh), dispatches between the two profile_marker_kernel launches only" % tag)
+METHOD = ("rocprofv3 --kernel-trace [--pmc ...] in separate passes over `bench.py --steps 2 --warmup 1 --serial` (tags ending "
+          "in c2: `--config 2 --steps 1 --warmup 1 --serial`) (profiles/collect_%s.sh), dispatches between the two "
+          "profile_marker_kernel launches only" % tag.replace("c2", ""))
 
 
 def klass(name):
@@ -176,7 +177,11 @@ if sq and rows:
         if g("SQ_LDS_IDX_ACTIVE"):
             d["lds_bank_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
         return d
-    doc = {"kernel": dom + "<BM,BN>", "method": METHOD,
+    # the other hand-written kernels of the round (whole-forward small-model kernel, one-pass metrics): same derived rates
+    others = {k: {"counters": {n: c["sum"] for n, c in cs.items()}, "launches": max(c["launches"] for c in cs.values()),
+                  "derived": derived({n: c["sum"] for n, c in cs.items()})}
+              for k, cs in sorted(sq.items()) if k in ("unet_fused_kernel", "pair_metrics_kernel", "cfg_update_kernel")}
+    doc = {"kernel": dom + "<BM,BN>", "method": METHOD, "other_kernels": others,
            "total": {"counters": dict(total), "derived": derived(total)},
            "instantiations": {k: {"counters": {n: c["sum"] for n, c in cs.items()}, "launches": max(c["launches"] for c in cs.values()),
                                   "derived": derived({n: c["sum"] for n, c in cs.items()})} for k, cs in sorted(members.items())}}
