@@ -322,7 +322,7 @@ __device__ __forceinline__ void fused_first(const FusedOp &op, const FusedLds &L
 
 // bilinear x2, align_corners=True (models.py:135,205-217) of an LDS tensor [G][w][w][c] -> [G][2w][2w][c]
 __device__ __forceinline__ void fused_upsample(const FusedOp &op, int G, int tid) {
-  const int wsh = op.wsh, w = 1 << wsh, cq = op.cs >> 2;
+  const int wsh = op.wsh, w = 1 << wsh, cq = op.kc * 4;          // kc 16-channel chunks; op.cs is the (padded) pixel stride
   const int W2 = 2 * w, n = G * W2 * W2 * cq;
   for (int i = pinned(tid); i < n; i += kThreads) {
     const int quad = i % cq, P = i / cq;
@@ -574,14 +574,23 @@ int launch_pack_fused_first(const float *w_oihw, float *dst, int cout, int C, in
 bool fused_eligible(int C, int c0p, int c1p) {
   if (C < 1 || C > 3) return false;
   if (c0p % 16 || c1p % 16 || c0p > 32 || c1p > 64) return false;
-  return 2 * c1p >= 3 * c0p && c1p <= 4 * c0p;     // buffer overlays of fused_lds() (H0 over C + E' + D; U1 inside B + S0..S2)
+  return c1p >= c0p && c1p <= 3 * c0p;             // buffer overlays of fused_lds(): U1 inside B + S0..S2 needs 16 s1 <= 64 s0
 }
 
+// pixel stride of an LDS activation tensor with c channels: c + 8 floats.  A ds_read_b128 is served in four groups of 16
+// lanes ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md) and a lane (pixel, s) reads 16 bytes at pixel * stride + 16 s: with
+// stride = c (64 / 128 / 256 bytes) 4 to 16 pixels of a group land on the same banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.73 measured, and with eight waves reading fragments the LDS, not the matrix pipe, paced the layers); a stride of 2 mod 4
+// sixteen-byte slots is conflict-free for every group and any tap shift.
+int fused_stride(int c) { return c + 8; }
+
 // LDS placement (floats) for G rows; see the lifetimes in fused_ops()
-//   [x G*768][low G*256][zero 16][tb offsets 16][head][K-split scratch][B: P1][C: S0 S1 S2 S3][E': P2 / H8][D: O2]     H0 overlays C + E' + D
+//   [x G*768][low G*256][zero 16][tb offsets 16][head][K-split scratch][parameters][time-bias rows]
+//   [B: P1][C: S0 S1 S2 S3][E': P2 / H8][D: O2]     H0 overlays C + E' + D (and extends the arena where that is shorter)
 FusedLds fused_lds(int G, int c0p, int c1p) {
   FusedLds L{};
-  const int a_sz = 64 * G * c0p, u = 16 * G * c1p;
+  const int s0 = fused_stride(c0p), s1 = fused_stride(c1p);
+  const int a_sz = 64 * G * s0, u = 16 * G * s1;
   L.x = 0;
   L.low = L.x + G * kXSlot;
   L.zero = L.low + G * 256;
@@ -596,6 +605,7 @@ FusedLds fused_lds(int G, int c0p, int c1p) {
   L.e = L.c + 4 * u;
   L.d = L.e + a_sz;
   L.total = L.d + 4 * u;
+  if (L.c + 256 * G * s0 > L.total) L.total = L.c + 256 * G * s0;      // H0 [256 G][s0]
   return L;
 }
 
@@ -608,7 +618,8 @@ size_t fused_lds_bytes(int G, int c0p, int c1p) { return (size_t)fused_lds(G, c0
 int fused_ops(const FusedModel &m, int G, FusedOp *ops) {
   const int c0p = m.c0p, c1p = m.c1p;
   const FusedLds L = fused_lds(G, c0p, c1p);
-  const int u = 16 * G * c1p, q = u / 4, gc = G * c1p;
+  const int s0 = fused_stride(c0p), s1 = fused_stride(c1p);            // pixel strides of the c0p- / c1p-channel tensors
+  const int u = 16 * G * s1, q = u / 4, gc = G * s1;
   const int S0 = L.c, S1 = L.c + u, S2 = L.c + 2 * u, S3 = L.c + 3 * u;
   const int H0 = L.c, P1 = L.b, H2 = L.c, O2 = L.d, P2 = L.e;
   const int H3 = S1, O3 = S2, P3 = S3, H4 = S3 + q, O4 = S3 + 2 * q, P4 = S3 + 3 * q, H5 = P4 + gc, O5 = P4 + 2 * gc;
@@ -637,44 +648,44 @@ int fused_ops(const FusedModel &m, int G, FusedOp *ops) {
   auto up = [&](int src, int dst, int wsh) {
     FusedOp &o = ops[n++];
     o = FusedOp{};
-    o.kind = FUSED_OP_UP; o.inA = src; o.out = dst; o.wsh = wsh; o.cs = c1p;
+    o.kind = FUSED_OP_UP; o.inA = src; o.out = dst; o.wsh = wsh; o.cs = s1; o.kc = k1;
   };
   const FusedBlockW *b = m.blk;
   {   // enc1.conv1
     FusedOp &o = ops[n++];
     o = FusedOp{};
-    o.kind = FUSED_OP_FIRST; o.w = m.wf; o.scale = b[0].c1.scale; o.shift = b[0].c1.shift; o.tb_off = b[0].tb_off; o.out = H0; o.cs = c0p;
+    o.kind = FUSED_OP_FIRST; o.w = m.wf; o.scale = b[0].c1.scale; o.shift = b[0].c1.shift; o.tb_off = b[0].tb_off; o.out = H0; o.cs = s0;
     o.ot = k0;
   }
   {   // enc1.conv2 + image skip + pool (enc1's full-resolution output has no other reader)
-    FusedOp &o = conv(b[0].c2, k0, k0, 4, H0, H0, c0p, k0, FUSED_E_IMAGE, 0, -1, c0p, P1);
+    FusedOp &o = conv(b[0].c2, k0, k0, 4, H0, H0, s0, k0, FUSED_E_IMAGE, 0, -1, s0, P1);
     o.wr = m.w3;
   }
-  conv(b[1].c1, k0, k1, 3, P1, P1, c0p, k0, FUSED_E_TIMEBIAS, b[1].tb_off, H2, c1p, -1);
+  conv(b[1].c1, k0, k1, 3, P1, P1, s0, k0, FUSED_E_TIMEBIAS, b[1].tb_off, H2, s1, -1);
   {
-    FusedOp &o = conv(b[1].c2, k1, k1, 3, H2, H2, c1p, k1, FUSED_E_SKIPCONV, 0, O2, c1p, P2);
-    o.wr = b[1].cr.w; o.br = b[1].cr.shift; o.kcr = k0; o.rA = P1; o.rB = P1; o.rcs = c0p; o.rcca = k0;
+    FusedOp &o = conv(b[1].c2, k1, k1, 3, H2, H2, s1, k1, FUSED_E_SKIPCONV, 0, O2, s1, P2);
+    o.wr = b[1].cr.w; o.br = b[1].cr.shift; o.kcr = k0; o.rA = P1; o.rB = P1; o.rcs = s0; o.rcca = k0;
   }
   const int lvl_in[3] = {P2, P3, P4}, lvl_h[3] = {H3, H4, H5}, lvl_o[3] = {O3, O4, O5}, lvl_p[3] = {P3, P4, -1};
   for (int j = 2; j <= 4; ++j) {   // enc3, enc4, bottleneck: identity residual
     const int wsh = 4 - j;         // 4x4, 2x2, 1x1
-    conv(b[j].c1, k1, k1, wsh, lvl_in[j - 2], lvl_in[j - 2], c1p, k1, FUSED_E_TIMEBIAS, b[j].tb_off, lvl_h[j - 2], c1p, -1);
-    FusedOp &o = conv(b[j].c2, k1, k1, wsh, lvl_h[j - 2], lvl_h[j - 2], c1p, k1, FUSED_E_IDENTITY, 0, lvl_o[j - 2], c1p, lvl_p[j - 2]);
-    o.rA = lvl_in[j - 2]; o.rcs = c1p;
+    conv(b[j].c1, k1, k1, wsh, lvl_in[j - 2], lvl_in[j - 2], s1, k1, FUSED_E_TIMEBIAS, b[j].tb_off, lvl_h[j - 2], s1, -1);
+    FusedOp &o = conv(b[j].c2, k1, k1, wsh, lvl_h[j - 2], lvl_h[j - 2], s1, k1, FUSED_E_IDENTITY, 0, lvl_o[j - 2], s1, lvl_p[j - 2]);
+    o.rA = lvl_in[j - 2]; o.rcs = s1;
   }
   const int d_up[3] = {U3, U2, U1}, d_src[3] = {O5, O6, O7}, d_skip[3] = {O4, O3, O2}, d_h[3] = {H6, H7, H8}, d_o[3] = {O6, O7, O8};
   for (int j = 5; j <= 7; ++j) {   // dec3, dec2, dec1: upsample, conv over [up | skip] read in place, 1x1 skip conv of the same concat
     const int d = j - 5, wsh = d + 1;
-    const int cout_p = j == 7 ? c0p : c1p, ot = cout_p / 16;
+    const int cout_p = j == 7 ? c0p : c1p, ot = cout_p / 16, so = j == 7 ? s0 : s1;
     up(d_src[d], d_up[d], wsh - 1);
-    conv(b[j].c1, 2 * k1, ot, wsh, d_up[d], d_skip[d], c1p, k1, FUSED_E_TIMEBIAS, b[j].tb_off, d_h[d], cout_p, -1);
-    FusedOp &o = conv(b[j].c2, ot, ot, wsh, d_h[d], d_h[d], cout_p, ot, FUSED_E_SKIPCONV, 0, d_o[d], cout_p, -1);
-    o.wr = b[j].cr.w; o.br = b[j].cr.shift; o.kcr = 2 * k1; o.rA = d_up[d]; o.rB = d_skip[d]; o.rcs = c1p; o.rcca = k1;
+    conv(b[j].c1, 2 * k1, ot, wsh, d_up[d], d_skip[d], s1, k1, FUSED_E_TIMEBIAS, b[j].tb_off, d_h[d], so, -1);
+    FusedOp &o = conv(b[j].c2, ot, ot, wsh, d_h[d], d_h[d], so, ot, FUSED_E_SKIPCONV, 0, d_o[d], so, -1);
+    o.wr = b[j].cr.w; o.br = b[j].cr.shift; o.kcr = 2 * k1; o.rA = d_up[d]; o.rB = d_skip[d]; o.rcs = s1; o.rcca = k1;
   }
   {
     FusedOp &o = ops[n++];
     o = FusedOp{};
-    o.kind = FUSED_OP_HEAD; o.inA = O8; o.cs = c0p;
+    o.kind = FUSED_OP_HEAD; o.inA = O8; o.cs = s0;
   }
   return n;
 }
