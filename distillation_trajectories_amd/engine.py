@@ -40,7 +40,8 @@ def sinusoid_frequencies(dim):
     return torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1 + 1e-8)))
 
 
-PLAN_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "gfx950.json")
+# (DT_PLAN_TABLE=file: another table, e.g. a candidate from tools/plan_search.py; DT_PLAN_TABLE= (empty): no table)
+PLAN_TABLE = os.environ.get("DT_PLAN_TABLE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans", "gfx950.json"))
 
 
 class _Plans:
