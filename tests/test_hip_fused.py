@@ -230,3 +230,15 @@ def test_fused_path_switches():
     big = engine.UNetHandle.for_module(small_model(0.5).to(DEV))
     big.set_fused(True)
     assert not big.fused_active(16, 16)
+
+
+def test_fused_randomised_models_batches_rules():
+    """tools/fuzz_fused.py: random small models (padded dims 16/32, 32/48, 32/64 from odd real channel counts, 1-3 image
+    channels), batches, update rules, plain / CFG / mixed batches, loops of 1..80 timesteps: forwards against the oracle, fused
+    loops against the layered per-timestep launches (a child process: the fuzzer is also a command-line tool)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fused.py"), "14", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "worst forward" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
