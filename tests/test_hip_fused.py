@@ -242,3 +242,31 @@ def test_fused_randomised_models_batches_rules():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fused.py"), "14", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "worst forward" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("sf", [0.1, 0.2])
+def test_fused_non_finite_image_stays_in_its_rows(sf):
+    """An Inf pixel in one image: that image's rows are non-finite, every other row -- also the one sharing its workgroup, whose
+    pixels sit in the same MFMA tiles at the 2x2 / 1x1 levels -- is bit-identical to a clean run (forward and sampler loop)."""
+    m = small_model(sf).to(DEV)
+    h = engine.UNetHandle.for_module(m)
+    B = 6
+    x = torch.randn(B, 3, 16, 16, generator=torch.Generator().manual_seed(8)).to(DEV)
+    tb = h.time_bias([30], [COND_NONE])
+    clean = h.forward(x, tb, 1, B).clone()
+    bad = x.clone()
+    bad[2, 1, 7, 9] = float("inf")                              # rows 2 and 3 share a workgroup (G = 2 rows)
+    got = h.forward(bad, tb, 1, B)
+    keep = [0, 1, 3, 4, 5]
+    assert torch.equal(got[keep], clean[keep]) and not torch.isfinite(got[2]).all() and torch.isfinite(clean).all()
+    n_steps = 3
+    ztab = torch.randn(n_steps * B, E, generator=torch.Generator().manual_seed(9)).to(DEV)
+    tbl = h.time_bias([30, 30, 20, 20, 10, 10], [COND_NONE, COND_ONE] * n_steps)
+    out = []
+    for x0 in (x, bad):
+        traj = torch.empty(n_steps + 1, B, E, device=DEV)
+        traj[0] = x0.reshape(B, E)
+        h.sample(RULE_PSAMPLE, traj, 16, 16, tbl, 2, [(1.0, 0.05, 0.02)] * n_steps, [True] * n_steps, z=ztab,
+                 z_shift=[i * B for i in range(n_steps)], w_scalar=3.0)
+        out.append(traj.clone())
+    assert torch.equal(out[1][:, keep], out[0][:, keep]) and not torch.isfinite(out[1][-1, 2]).all()
